@@ -1,0 +1,1361 @@
+// az_engine.hip — MI355X (gfx950) self-play engine: batched PUCT tree search + rollout loop.
+//
+// One 64-lane wavefront owns one concurrent game ("slot").  Per tick (az_engine_advance) a slot
+//   consumes the network result of its outstanding request  -> expand + backup   (mcts.py:54-66,82-89,145-152)
+//   then runs playouts: select by wave argmax of PUCT          (mcts.py:38-52,68-80,139-142)
+//   applying bitboard moves until it needs the network again    (az_games.h)
+//   and, every S playouts, the agent's move step               (mcts.py:155-162,192-203; alphazerobot.py:71-93;
+//                                                               game_utils.py:156-197)
+// Tree arithmetic is IEEE double with one rounding per operation (-ffp-contract=off), i.e. the
+// reference's Python-float arithmetic: given the same (priors, value) inputs and the same random
+// draws, visit counts and Q values are bit-identical to mcts.py.
+//
+// HBM layout (all SoA, index = (slot*2 + half)*cap + node):
+//   N   u32   visit count                       Q  f64  mean value (viewpoint of the player who moved in)
+//   P   f64   prior                              C0 u32  index of first child (children are contiguous,
+//   META u32  action (low 16) | n_children<<16          ascending action = dict insertion order of mcts.py:62-64)
+// so one select level is ONE coalesced read of {N,Q,P,C0,META}[c0 .. c0+n) by lanes 0..n-1.
+// Each slot has two pool halves; re-rooting compacts the kept subtree into the other half
+// (Cheney copy, breadth-first) when the free tail could not hold another search.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/az_engine.h"
+#include "az_games.h"
+
+#define NONE32 0xFFFFFFFFu
+
+enum { PH_IDLE = 0, PH_RUN = 1, PH_MOVE = 2, PH_WAIT_ROOT = 3, PH_WAIT_LEAF = 4, PH_SEARCH_DONE = 5, PH_NEED_ROOT = 6 };
+enum { ST_MOVES = 0, ST_SIMS, ST_EVALS, ST_TERM, ST_DEPTH, ST_CHILDREN, ST_NODES, ST_COMPACT, ST_N };
+
+struct PwPlan { // numpy pairwise-sum recursion for a length-A vector, flattened (see np_sum_sparse)
+    int n_blocks;
+    int lo[16], len[16];
+    int n_ops;
+    int ops[32]; // >=0: push block i, -1: add top two
+};
+
+struct Params {
+    // geometry / config
+    AzGeom geom;
+    int game, A, maxc, max_plies, obs_elems, pstride;
+    int G, S, use_dirichlet, keep_tree, backup, rng_mode, max_sims_per_tick, manual_moves;
+    uint32_t cap, need_per_move;
+    double c_puct, one_minus_ratio, alpha, inv_temp;
+    uint64_t seed;
+    long long n_games, max_games;
+    AzState start;
+    PwPlan pw;
+    // node pools
+    uint32_t *N, *C0, *META;
+    double *Q, *P;
+    // per slot
+    int *phase, *gid, *ply, *sims, *which, *depth, *leaf_ply;
+    uint32_t *root, *alloc, *leaf_node, *path;
+    uint64_t *bb0, *bb1, *leaf_bb0, *leaf_bb1;
+    unsigned long long *stats; // [G][ST_N]
+    // global counters
+    unsigned long long *next_game, *games_done;
+    unsigned int *faults;
+    // injected randomness
+    const double *etas, *us;
+    double *eta_buf; // [G][maxc] Dirichlet draw staged with the root request (Philox mode)
+    // records
+    int *rec_len;
+    float *rec_ret0;
+    uint64_t *rec_states;
+    uint16_t *rec_move, *rec_child_action;
+    uint8_t *rec_nchild;
+    uint32_t *rec_child_visits;
+    double *rec_value;
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) {
+    uint32_t lo = rflu((uint32_t)v), hi = rflu((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        double o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned int wave_or(unsigned int v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v |= (unsigned int)__shfl_xor((int)v, off);
+    return v;
+}
+__device__ __forceinline__ uint64_t lanes_below(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG: stream = (seed, game id), counter = (ply, purpose, index, draw)
+struct Philox {
+    uint32_t k0, k1, c0, c1, c2, c3;
+    uint32_t out[4];
+    int have;
+};
+__device__ __forceinline__ void philox_init(Philox &r, uint64_t seed, uint32_t gid, uint32_t ply, uint32_t purpose, uint32_t idx) {
+    r.k0 = (uint32_t)seed;
+    r.k1 = (uint32_t)(seed >> 32);
+    r.c0 = 0;
+    r.c1 = idx;
+    r.c2 = (ply << 8) | purpose;
+    r.c3 = gid;
+    r.have = 0;
+}
+__device__ __forceinline__ void philox_block(Philox &r) {
+    uint32_t c0 = r.c0, c1 = r.c1, c2 = r.c2, c3 = r.c3, k0 = r.k0, k1 = r.k1;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    r.out[0] = c0; r.out[1] = c1; r.out[2] = c2; r.out[3] = c3;
+    r.c0++;
+    r.have = 2;
+}
+__device__ __forceinline__ double philox_u01(Philox &r) { // [0,1), 53 bits
+    if (!r.have) philox_block(r);
+    r.have--;
+    uint64_t x = ((uint64_t)r.out[2 * r.have] << 32) | r.out[2 * r.have + 1];
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ double philox_gamma(Philox &r, double alpha) { // Marsaglia-Tsang; alpha < 1 boosted
+    double boost = 1.0;
+    if (alpha < 1.0) {
+        boost = pow(1.0 - philox_u01(r), 1.0 / alpha);
+        alpha += 1.0;
+    }
+    double d = alpha - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (int it = 0; it < 64; it++) {
+        double u1 = 1.0 - philox_u01(r), u2 = philox_u01(r);
+        double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        double u = 1.0 - philox_u01(r);
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v * boost;
+    }
+    return d * boost;
+}
+
+// ------------------------------------------------------------------------------------------------
+// numpy arithmetic on the agent's move step (alphazerobot.py:13-14,78,84), lanes = root children.
+__device__ __forceinline__ double np_pow(double x, double e) { // ndarray ** python-float fast paths
+    if (e == 1.0) return x;
+    if (e == 2.0) return x * x;
+    if (e == 0.5) return sqrt(x);
+    if (e == -1.0) return 1.0 / x;
+    return pow(x, e);
+}
+
+// np.sum (pairwise, 8 accumulators per <=128 block) of the dense length-A vector whose only non-zeros
+// are v[k] at index act[k], k < nc, ascending.  Executed redundantly by all lanes (uniform control).
+__device__ double np_sum_sparse(const PwPlan &pw, double v, int act, int nc) {
+    double stack[6];
+    int sp = 0;
+    int k = 0; // children are consumed in ascending index order across ascending blocks
+    for (int o = 0; o < pw.n_ops; o++) {
+        int op = pw.ops[o];
+        if (op < 0) {
+            double b = stack[--sp], a = stack[--sp];
+            stack[sp++] = a + b;
+            continue;
+        }
+        int lo = pw.lo[op], n = pw.len[op];
+        double res;
+        if (n < 8) {
+            res = 0.0;
+            while (k < nc) {
+                int a = __shfl(act, k);
+                if (a >= lo + n) break;
+                res += __shfl(v, k);
+                k++;
+            }
+        } else {
+            double r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, tail = 0;
+            int body = n - (n % 8);
+            int k0 = k;
+            while (k < nc) {
+                int a = __shfl(act, k);
+                if (a >= lo + n) break;
+                int j = a - lo;
+                double x = __shfl(v, k);
+                if (j < body) {
+                    switch (j & 7) {
+                    case 0: r0 += x; break;
+                    case 1: r1 += x; break;
+                    case 2: r2 += x; break;
+                    case 3: r3 += x; break;
+                    case 4: r4 += x; break;
+                    case 5: r5 += x; break;
+                    case 6: r6 += x; break;
+                    default: r7 += x; break;
+                    }
+                }
+                k++;
+            }
+            res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+            for (int kk = k0; kk < k; kk++) { // remainder elements are added after the tree, in order
+                int j = __shfl(act, kk) - lo;
+                if (j >= body) res += __shfl(v, kk);
+            }
+            (void)tail;
+        }
+        stack[sp++] = res;
+    }
+    return stack[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Pool {
+    uint32_t *N, *C0, *META;
+    double *Q, *P;
+};
+__device__ __forceinline__ Pool pool_at(const Params &p, int g, int half) {
+    size_t base = ((size_t)g * 2 + half) * p.cap;
+    Pool q = {p.N + base, p.C0 + base, p.META + base, p.Q + base, p.P + base};
+    return q;
+}
+__device__ __forceinline__ void pool_init_root(const Pool &t, int lane) {
+    if (lane == 0) {
+        t.N[0] = 0;
+        t.Q[0] = 0.0;
+        t.P[0] = 0.0;
+        t.C0[0] = NONE32;
+        t.META[0] = 0;
+    }
+}
+
+template <int NP> struct Path { // depth d lives in lane d&63, register d>>6
+    uint32_t r[NP];
+    __device__ __forceinline__ void set(int lane, int d, uint32_t node) {
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+            if ((d >> 6) == i && lane == (d & 63)) r[i] = node;
+    }
+};
+
+// Enumerate the legal actions of `s` in ascending order, one wave.  For each of this lane's (<=3)
+// moves: slot index k (position in the ascending list) and action id.  Returns total count.
+template <int GAME>
+__device__ __forceinline__ int enum_moves(const AzState &s, const AzGeom &g, int lane, int k[3], int act[3], int &mine) {
+    if (GAME == AZG_CONNECT_FOUR) {
+        uint32_t m = az_c4_legal_mask(s);
+        bool ok = lane < 7 && ((m >> lane) & 1u);
+        mine = ok ? 1 : 0;
+        k[0] = __popc(m & ((1u << lane) - 1u));
+        act[0] = lane;
+        return __popc(m);
+    } else {
+        uint32_t mv = lane < g.cells ? az_bt_cell_moves(s, g, lane) : 0u;
+        uint64_t b0 = __ballot(mv & 1u), b1 = __ballot(mv & 2u), b2 = __ballot(mv & 4u);
+        uint64_t below = lanes_below(lane);
+        int off = __popcll(b0 & below) + __popcll(b1 & below) + __popcll(b2 & below);
+        int me = s.ply & 1;
+        mine = 0;
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+            if (mv & (1u << d)) {
+                k[mine] = off + mine;
+                act[mine] = az_bt_encode(lane, me, d, (mv >> (4 + d)) & 1u);
+                mine++;
+            }
+        return __popcll(b0) + __popcll(b1) + __popcll(b2);
+    }
+}
+
+template <int GAME> __device__ __forceinline__ void write_obs(const Params &p, const AzState &s, float *obs, int lane) {
+    for (int i = lane; i < p.obs_elems; i += 64) obs[i] = az_obs_elem<GAME>(s, p.geom, i);
+}
+
+// Cheney copy of the subtree under `root` from pool `a` into pool `b` (node 0 = new root).
+// Returns the number of live nodes.  Children stay contiguous and in ascending-action order.
+__device__ uint32_t compact_subtree(const Pool &a, const Pool &b, uint32_t root, int lane) {
+    if (lane == 0) {
+        b.N[0] = a.N[root];
+        b.Q[0] = a.Q[root];
+        b.P[0] = a.P[root];
+        b.C0[0] = a.C0[root]; // still an OLD index until scanned
+        b.META[0] = a.META[root];
+    }
+    __threadfence_block();
+    uint32_t s = 0, f = 1;
+    while (s < f) {
+        uint32_t cnt = f - s < 64 ? f - s : 64;
+        uint32_t oc0 = NONE32;
+        int nch = 0;
+        if ((uint32_t)lane < cnt) {
+            oc0 = b.C0[s + lane];
+            nch = oc0 == NONE32 ? 0 : (int)(b.META[s + lane] >> 16);
+        }
+        int incl = wave_incl_scan(nch, lane);
+        int total = __shfl(incl, 63);
+        uint32_t dst = f + (uint32_t)(incl - nch);
+        if (nch > 0) b.C0[s + lane] = dst;
+        int mx = nch;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            int o = __shfl_xor(mx, off);
+            mx = o > mx ? o : mx;
+        }
+        for (int k = 0; k < mx; k++)
+            if (k < nch) {
+                uint32_t si = oc0 + k, di = dst + k;
+                b.N[di] = a.N[si];
+                b.Q[di] = a.Q[si];
+                b.P[di] = a.P[si];
+                b.C0[di] = a.C0[si];
+                b.META[di] = a.META[si];
+            }
+        __threadfence_block(); // the next chunk reads what this one wrote (same wave, global memory)
+        f += (uint32_t)total;
+        s += cnt;
+    }
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Slot registers shared by the kernels
+struct SlotRegs {
+    int gid, sims, half;
+    uint32_t root, alloc;
+    AzState rs;
+};
+__device__ __forceinline__ void slot_load(const Params &p, int g, SlotRegs &r) {
+    r.gid = rfl(p.gid[g]);
+    r.rs.bb0 = rfl64(p.bb0[g]);
+    r.rs.bb1 = rfl64(p.bb1[g]);
+    r.rs.ply = rfl(p.ply[g]);
+    r.sims = rfl(p.sims[g]);
+    r.half = rfl(p.which[g]);
+    r.root = rflu(p.root[g]);
+    r.alloc = rflu(p.alloc[g]);
+}
+__device__ __forceinline__ void slot_store(const Params &p, int g, const SlotRegs &r, int phase) {
+    p.phase[g] = phase;
+    p.gid[g] = r.gid;
+    p.bb0[g] = r.rs.bb0;
+    p.bb1[g] = r.rs.bb1;
+    p.ply[g] = r.rs.ply;
+    p.sims[g] = r.sims;
+    p.which[g] = r.half;
+    p.root[g] = r.root;
+    p.alloc[g] = r.alloc;
+}
+
+// mcts.py:82-89 update_recursive along the recorded path: node at depth d gets x * (-1)^(depth-d)
+template <int NP>
+__device__ __forceinline__ void backup_path(const Pool &t, const Path<NP> &path, int depth, double x, int lane) {
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        int d = i * 64 + lane;
+        if (d <= depth) {
+            uint32_t nd = path.r[i];
+            double xv = ((depth - d) & 1) ? -x : x;
+            uint32_t nn = t.N[nd];
+            double q = t.Q[nd];
+            t.Q[nd] = ((double)nn * q + xv) / (double)(nn + 1); // mcts.py:83
+            t.N[nd] = nn + 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel 1 (hot): consume network results, then MCTS.playout until the network is needed again.
+template <int GAME, int NP>
+__global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *__restrict__ priors,
+                                                         const float *__restrict__ values, float *__restrict__ obs_out) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= p.G) return;
+    int ph = rfl(p.phase[g]);
+    if (ph != PH_RUN && ph != PH_WAIT_LEAF && ph != PH_WAIT_ROOT) return;
+
+    const AzGeom &geom = p.geom;
+    SlotRegs sr;
+    slot_load(p, g, sr);
+    Pool t = pool_at(p, g, sr.half);
+    unsigned long long st_sims = 0, st_evals = 0, st_term = 0, st_depth = 0, st_children = 0, st_nodes = 0;
+    unsigned int fault = 0;
+    Path<NP> path;
+#pragma unroll
+    for (int i = 0; i < NP; i++) path.r[i] = 0;
+
+    // ---- 1. consume the outstanding request ----------------------------------------------------
+    if (ph == PH_WAIT_LEAF || ph == PH_WAIT_ROOT) {
+        const float *pri = priors + (size_t)g * p.A;
+        AzState ls;
+        uint32_t node;
+        int depth = 0;
+        if (ph == PH_WAIT_LEAF) {
+            ls.bb0 = rfl64(p.leaf_bb0[g]);
+            ls.bb1 = rfl64(p.leaf_bb1[g]);
+            ls.ply = rfl(p.leaf_ply[g]);
+            node = rflu(p.leaf_node[g]);
+            depth = rfl(p.depth[g]);
+#pragma unroll
+            for (int i = 0; i < NP; i++) path.r[i] = p.path[(size_t)g * p.pstride + i * 64 + lane];
+        } else {
+            ls = sr.rs;
+            node = sr.root;
+        }
+        int k[3], act[3], mine;
+        int n = enum_moves<GAME>(ls, geom, lane, k, act, mine);
+        uint32_t c0 = rflu(t.C0[node]);
+        bool fresh = (c0 == NONE32);
+        if (fresh) {
+            if (sr.alloc + (uint32_t)n > p.cap) {
+                fault |= AZ_FAULT_POOL_EXHAUSTED;
+                n = 0;
+                mine = 0;
+            }
+            c0 = sr.alloc;
+        }
+        double eta[3] = {0.0, 0.0, 0.0};
+        if (ph == PH_WAIT_ROOT) { // mcts.py:182-190
+            // injected draws (parity mode) or the Philox draws az_move_kernel staged with the request
+            const double *e = p.rng_mode == AZ_RNG_INJECTED
+                                  ? p.etas + ((size_t)sr.gid * p.max_plies + sr.rs.ply) * p.maxc
+                                  : p.eta_buf + (size_t)g * p.maxc;
+            for (int j = 0; j < mine; j++) eta[j] = e[k[j]];
+        }
+        for (int j = 0; j < mine; j++) {
+            float pf = pri[act[j]];
+            if (!(pf == pf)) fault |= AZ_FAULT_BAD_PRIOR;
+            double pv = (double)pf;
+            if (ph == PH_WAIT_ROOT) pv = p.one_minus_ratio * pv + 0.25 * eta[j]; // literal 0.25: mcts.py:189
+            uint32_t i = c0 + (uint32_t)k[j];
+            t.P[i] = pv;
+            if (fresh) { // mcts.py:63-64: Node(parent, prior)
+                t.N[i] = 0;
+                t.Q[i] = 0.0;
+                t.C0[i] = NONE32;
+                t.META[i] = (uint32_t)act[j];
+            }
+        }
+        if (fresh && n > 0) {
+            if (lane == 0) {
+                t.C0[node] = c0;
+                t.META[node] = (t.META[node] & 0xFFFFu) | ((uint32_t)n << 16);
+            }
+            sr.alloc += (uint32_t)n;
+            st_nodes += (unsigned long long)n;
+        }
+        if (ph == PH_WAIT_LEAF) { // mcts.py:152: node.update_recursive(-leaf_value)
+            float vf = values[g];
+            if (!(vf == vf)) fault |= AZ_FAULT_BAD_PRIOR;
+            backup_path<NP>(t, path, depth, -(double)vf, lane);
+            sr.sims++;
+            st_sims++;
+            st_depth += (unsigned long long)depth;
+        }
+        __threadfence_block();
+    }
+
+    // ---- 2. playouts until the network is needed again -------------------------------------------
+    int budget = p.max_sims_per_tick;
+    int next_phase = PH_RUN;
+    for (;;) {
+        if (__ballot(fault != 0)) { // faults are raised per lane: make the exit wave-uniform
+            next_phase = PH_IDLE;
+            break;
+        }
+        if (sr.sims >= p.S) { // the agent's move step runs in az_move_kernel
+            next_phase = PH_MOVE;
+            break;
+        }
+        if (budget-- <= 0) {
+            next_phase = PH_RUN;
+            break;
+        }
+        // ================= MCTS.playout (mcts.py:126-153) =================
+        AzState s = sr.rs;
+        uint32_t node = sr.root;
+        uint32_t np_ = rflu(t.N[node]);
+        uint32_t c0 = rflu(t.C0[node]);
+        int nc = c0 == NONE32 ? 0 : (int)(rflu(t.META[node]) >> 16);
+        int depth = 0, term = 0;
+        float ret0 = 0.f;
+        int mover = s.ply & 1;
+        path.set(lane, 0, node);
+        while (nc > 0 && !term) {
+            mover = s.ply & 1;
+            double val = -INFINITY;
+            uint32_t cn = 0, cc0 = NONE32, cmeta = 0;
+            if (lane < nc) {
+                uint32_t i = c0 + lane;
+                cn = t.N[i];
+                double q = t.Q[i], pp = t.P[i];
+                cc0 = t.C0[i];
+                cmeta = t.META[i];
+                val = q + ((p.c_puct * pp) * sqrt((double)np_)) / (double)(cn + 1); // mcts.py:78
+            }
+            double mx = wave_max(val);
+            unsigned long long eq = __ballot(val == mx);
+            int best = eq ? __ffsll(eq) - 1 : 0; // first maximum in child order (mcts.py:50)
+            if (!eq) fault |= AZ_FAULT_BAD_PRIOR;
+            st_children += (unsigned long long)nc;
+            node = c0 + (uint32_t)best;
+            np_ = rflu(__shfl(cn, best));
+            c0 = rflu(__shfl(cc0, best));
+            uint32_t meta = rflu(__shfl(cmeta, best));
+            nc = c0 == NONE32 ? 0 : (int)(meta >> 16);
+            term = az_apply<GAME>(s, geom, (int)(meta & 0xFFFFu), &ret0);
+            depth++;
+            path.set(lane, depth, node);
+        }
+        if (term) { // mcts.py:148-152: leaf_value = -player_return(mover); update_recursive(-leaf_value)
+            double x = mover == 0 ? (double)ret0 : -(double)ret0;
+            backup_path<NP>(t, path, depth, x, lane);
+            __threadfence_block();
+            sr.sims++;
+            st_sims++;
+            st_term++;
+            st_depth += (unsigned long long)depth;
+            continue;
+        }
+        // non-terminal leaf: ask the network (mcts.py:146)
+        write_obs<GAME>(p, s, obs_out + (size_t)g * p.obs_elems, lane);
+        st_evals++;
+        if (lane == 0) {
+            p.leaf_bb0[g] = s.bb0;
+            p.leaf_bb1[g] = s.bb1;
+            p.leaf_ply[g] = s.ply;
+            p.leaf_node[g] = node;
+            p.depth[g] = depth;
+        }
+#pragma unroll
+        for (int i = 0; i < NP; i++) p.path[(size_t)g * p.pstride + i * 64 + lane] = path.r[i];
+        next_phase = PH_WAIT_LEAF;
+        break;
+    }
+
+    // ---- 3. write the slot back ----------------------------------------------------------------
+    fault = wave_or(fault);
+    if (lane == 0) {
+        slot_store(p, g, sr, next_phase);
+        unsigned long long *st = p.stats + (size_t)g * ST_N;
+        st[ST_SIMS] += st_sims;
+        st[ST_EVALS] += st_evals;
+        st[ST_TERM] += st_term;
+        st[ST_DEPTH] += st_depth;
+        st[ST_CHILDREN] += st_children;
+        st[ST_NODES] += st_nodes;
+        if (fault) atomicOr(p.faults, fault);
+    }
+}
+
+// mcts.update_root(action) (mcts.py:192-203) + the pool bookkeeping it implies here.
+// `sel` = index of the chosen child among the root's children, or -1 for "fresh tree".
+__device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, int lane, unsigned int &fault,
+                       unsigned long long &st_compact) {
+    uint32_t c0 = rflu(t.C0[sr.root]);
+    if (sel < 0 || c0 == NONE32) { // root.is_leaf() or keep_search_tree=False: a new root Node
+        sr.root = 0;
+        sr.alloc = 1;
+        pool_init_root(t, lane);
+        __threadfence_block();
+        return;
+    }
+    sr.root = c0 + (uint32_t)sel;
+    if (sr.alloc + p.need_per_move > p.cap) {
+        Pool o = pool_at(p, g, sr.half ^ 1);
+        sr.alloc = compact_subtree(t, o, sr.root, lane);
+        sr.root = 0;
+        sr.half ^= 1;
+        t = o;
+        st_compact++;
+        if (sr.alloc + p.need_per_move > p.cap) fault |= AZ_FAULT_POOL_EXHAUSTED;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel 2 (cold): AlphaZeroBot.step's tail + play_game_self's loop body for slots whose S playouts are
+// done, game turnover, and the root-evaluation request of the next search.
+template <int GAME>
+__global__ __launch_bounds__(256) void az_move_kernel(Params p, float *__restrict__ obs_out) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= p.G) return;
+    int ph = rfl(p.phase[g]);
+    if (ph != PH_MOVE && ph != PH_NEED_ROOT) return;
+    const AzGeom &geom = p.geom;
+    SlotRegs sr;
+    slot_load(p, g, sr);
+    Pool t = pool_at(p, g, sr.half);
+    unsigned long long st_moves = 0, st_evals = 0, st_compact = 0;
+    unsigned int fault = 0;
+
+    if (ph == PH_MOVE) {
+        if (p.manual_moves) {
+            if (lane == 0) p.phase[g] = PH_SEARCH_DONE;
+            return;
+        }
+        uint32_t c0 = rflu(t.C0[sr.root]);
+        int nc = c0 == NONE32 ? 0 : (int)(rflu(t.META[sr.root]) >> 16);
+        uint32_t cn = 0;
+        int cact = 0;
+        double cq = 0.0;
+        if (lane < nc) {
+            cn = t.N[c0 + lane];
+            cq = t.Q[c0 + lane];
+            cact = (int)(t.META[c0 + lane] & 0xFFFFu);
+        }
+        long long tot = wave_sum_ll((long long)cn);
+        if (nc == 0 || tot <= 0) fault |= AZ_FAULT_NO_VISITS;
+        if (sr.rs.ply >= p.max_plies || sr.gid >= p.max_games || sr.gid < 0) fault |= AZ_FAULT_PLY_OVERFLOW;
+        if (fault) {
+            if (lane == 0) {
+                p.phase[g] = PH_IDLE;
+                atomicOr(p.faults, fault);
+            }
+            return;
+        }
+        // value target (game_utils.py:168-194)
+        double target = 0.0;
+        if (p.backup == AZ_BACKUP_SOFT_Z) {
+            target = -t.Q[sr.root];
+        } else if (p.backup == AZ_BACKUP_A0C) {
+            target = wave_max(lane < nc ? (cn > 0 ? cq : -99.0) : -INFINITY);
+        } else if (p.backup == AZ_BACKUP_OFF_POLICY) { // A0GB: walk the most-visited line
+            uint32_t node = sr.root, nn = rflu(t.N[sr.root]);
+            double value = 0.0, mult = 1.0;
+            uint32_t kc0 = c0;
+            int knc = nc;
+            while (knc > 0) {
+                value = t.Q[node];
+                double sc = -INFINITY;
+                uint32_t n2 = 0, c2 = NONE32, m2 = 0;
+                if (lane < knc) {
+                    n2 = t.N[kc0 + lane];
+                    c2 = t.C0[kc0 + lane];
+                    m2 = t.META[kc0 + lane];
+                    sc = n2 > 0 ? (double)n2 + t.P[kc0 + lane] : -99.0;
+                }
+                double mx = wave_max(sc);
+                int best = __ffsll((unsigned long long)__ballot(sc == mx)) - 1;
+                node = kc0 + (uint32_t)best;
+                nn = rflu(__shfl(n2, best));
+                kc0 = rflu(__shfl(c2, best));
+                knc = kc0 == NONE32 ? 0 : (int)(rflu(__shfl(m2, best)) >> 16);
+                mult *= -1.0;
+            }
+            if (nn > 0) {
+                value = t.Q[node];
+                mult *= -1.0;
+            }
+            target = value * mult;
+        }
+        // action sampling: visit fractions -> remove_illegal_actions -> temperature -> np.random.choice
+        double nv = lane < nc ? (double)cn / (double)tot : 0.0; // mcts.py:162
+        double ssum = np_sum_sparse(p.pw, nv, cact, nc);        // alphazerobot.py:13
+        if (ssum > 1e-6) nv = nv / ssum; else nv = lane < nc ? 1.0 / (double)nc : 0.0;
+        double ap = lane < nc ? np_pow(nv, p.inv_temp) : 0.0; // alphazerobot.py:78
+        double tot2 = 0.0;
+        for (int kk = 0; kk < nc; kk++) tot2 += __shfl(ap, kk);
+        ap = ap / tot2;
+        double run = 0.0, mycdf = 0.0; // np.random.choice: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u,'right')
+        for (int kk = 0; kk < nc; kk++) {
+            run += __shfl(ap, kk);
+            if (lane == kk) mycdf = run;
+        }
+        mycdf = mycdf / run;
+        double u;
+        if (p.rng_mode == AZ_RNG_INJECTED) u = p.us[(size_t)sr.gid * p.max_plies + sr.rs.ply];
+        else {
+            Philox r;
+            philox_init(r, p.seed, (uint32_t)sr.gid, (uint32_t)sr.rs.ply, 1u, 0u);
+            u = philox_u01(r);
+        }
+        unsigned long long gt = __ballot(lane < nc && mycdf > u);
+        int sel = gt ? __ffsll(gt) - 1 : nc - 1;
+        while (sel > 0 && __shfl(cn, sel) == 0) sel--; // rounding corner: never pick an unvisited child
+        int action = rfl(__shfl(cact, sel));
+        // the example record (game_utils.py:169): state + root child visits; pi = N/sum is formed on the host
+        size_t ri = (size_t)sr.gid * p.max_plies + sr.rs.ply;
+        if (lane == 0) {
+            p.rec_states[ri * 2] = sr.rs.bb0;
+            p.rec_states[ri * 2 + 1] = sr.rs.bb1;
+            p.rec_move[ri] = (uint16_t)action;
+            p.rec_nchild[ri] = (uint8_t)nc;
+            p.rec_value[ri] = target;
+        }
+        if (lane < nc) {
+            p.rec_child_action[ri * p.maxc + lane] = (uint16_t)cact;
+            p.rec_child_visits[ri * p.maxc + lane] = cn;
+        }
+        st_moves++;
+        float ret0 = 0.f;
+        int term = az_apply<GAME>(sr.rs, geom, action, &ret0); // game_utils.py:197
+        sr.sims = 0;
+        if (term) {
+            unsigned long long nxt = 0;
+            if (lane == 0) {
+                p.rec_len[sr.gid] = sr.rs.ply - p.start.ply;
+                p.rec_ret0[sr.gid] = ret0;
+                __threadfence(); // records before the done-count
+                atomicAdd(p.games_done, 1ull);
+                nxt = atomicAdd(p.next_game, 1ull);
+            }
+            nxt = ((unsigned long long)rflu((uint32_t)(nxt >> 32)) << 32) | rflu((uint32_t)nxt);
+            if ((long long)nxt >= p.n_games) {
+                sr.gid = -1;
+                if (lane == 0) {
+                    slot_store(p, g, sr, PH_IDLE);
+                    p.stats[(size_t)g * ST_N + ST_MOVES] += st_moves;
+                }
+                return;
+            }
+            sr.gid = (int)nxt;
+            sr.rs = p.start;
+            reroot(p, g, sr, t, -1, lane, fault, st_compact);
+        } else {
+            reroot(p, g, sr, t, p.keep_tree ? sel : -1, lane, fault, st_compact);
+        }
+        ph = p.use_dirichlet ? PH_NEED_ROOT : PH_RUN;
+    }
+    if (ph == PH_NEED_ROOT) { // expand_root_dirichlet's policy_fn(state) (mcts.py:183)
+        if (p.rng_mode == AZ_RNG_PHILOX) { // np.random.dirichlet(0.3 * ones(n_legal)) (mcts.py:187): gamma draws / their sum
+            int k[3], act[3], mine;
+            enum_moves<GAME>(sr.rs, geom, lane, k, act, mine);
+            double eta[3], part = 0.0;
+            for (int j = 0; j < mine; j++) {
+                Philox r;
+                philox_init(r, p.seed, (uint32_t)sr.gid, (uint32_t)sr.rs.ply, 0u, (uint32_t)k[j]);
+                eta[j] = philox_gamma(r, p.alpha);
+                part += eta[j];
+            }
+            double inv = 1.0 / wave_sum_d(part);
+            for (int j = 0; j < mine; j++) p.eta_buf[(size_t)g * p.maxc + k[j]] = eta[j] * inv;
+        }
+        write_obs<GAME>(p, sr.rs, obs_out + (size_t)g * p.obs_elems, lane);
+        st_evals++;
+        ph = PH_WAIT_ROOT;
+    }
+    fault = wave_or(fault);
+    if (lane == 0) {
+        slot_store(p, g, sr, fault ? PH_IDLE : ph);
+        unsigned long long *st = p.stats + (size_t)g * ST_N;
+        st[ST_MOVES] += st_moves;
+        st[ST_EVALS] += st_evals;
+        st[ST_COMPACT] += st_compact;
+        if (fault) atomicOr(p.faults, fault);
+    }
+}
+
+// MCTS.update_root for manual_moves engines (AlphaZeroBot.step outside the self-play loop).
+template <int GAME>
+__global__ __launch_bounds__(256) void az_update_root_kernel(Params p, const int *__restrict__ actions, int keep_subtree) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= p.G) return;
+    int action = rfl(actions[g]);
+    int ph = rfl(p.phase[g]);
+    if (action < 0 || ph == PH_IDLE) return;
+    SlotRegs sr;
+    slot_load(p, g, sr);
+    Pool t = pool_at(p, g, sr.half);
+    unsigned int fault = 0;
+    unsigned long long st_compact = 0;
+    uint32_t c0 = rflu(t.C0[sr.root]);
+    int nc = c0 == NONE32 ? 0 : (int)(rflu(t.META[sr.root]) >> 16);
+    int cact = lane < nc ? (int)(t.META[c0 + lane] & 0xFFFFu) : -1;
+    unsigned long long hit = __ballot(cact == action);
+    int sel = (keep_subtree && hit) ? __ffsll(hit) - 1 : -1;
+    float ret0 = 0.f;
+    int term = az_apply<GAME>(sr.rs, p.geom, action, &ret0);
+    sr.sims = 0;
+    reroot(p, g, sr, t, sel, lane, fault, st_compact);
+    fault = wave_or(fault);
+    if (lane == 0) {
+        slot_store(p, g, sr, (term || fault) ? PH_IDLE : (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN));
+        p.stats[(size_t)g * ST_N + ST_COMPACT] += st_compact;
+        if (fault) atomicOr(p.faults, fault);
+    }
+}
+
+__global__ void az_reset_kernel(Params p) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.G) return;
+    bool active = (long long)g < p.n_games;
+    p.phase[g] = active ? (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN) : PH_IDLE;
+    p.gid[g] = active ? g : -1;
+    p.bb0[g] = p.start.bb0;
+    p.bb1[g] = p.start.bb1;
+    p.ply[g] = p.start.ply;
+    p.sims[g] = 0;
+    p.which[g] = 0;
+    p.root[g] = 0;
+    p.alloc[g] = 1;
+    p.depth[g] = 0;
+    p.leaf_node[g] = 0;
+    size_t base = (size_t)g * 2 * p.cap;
+    p.N[base] = 0;
+    p.Q[base] = 0.0;
+    p.P[base] = 0.0;
+    p.C0[base] = NONE32;
+    p.META[base] = 0;
+    for (int i = 0; i < ST_N; i++) p.stats[(size_t)g * ST_N + i] = 0;
+    if (g == 0) {
+        *p.next_game = (unsigned long long)(p.n_games < p.G ? p.n_games : p.G);
+        *p.games_done = 0;
+        *p.faults = 0;
+    }
+}
+
+// ================================================================================================
+// host side: C ABI
+struct az_engine {
+    az_config cfg;
+    Params p;
+    az_sizes sizes;
+    std::string err;
+    std::vector<void *> dev_allocs;
+    bool reset_done = false;
+    int64_t n_games = 0;
+    double *d_etas = nullptr, *d_us = nullptr;
+    int *d_actions = nullptr;
+    int64_t ticks = 0;
+    int64_t inj_games = 0;
+    // host mirrors for export
+    std::vector<int32_t> h_len;
+    std::vector<float> h_ret0;
+    std::vector<uint64_t> h_states;
+    std::vector<uint16_t> h_move, h_child_action;
+    std::vector<uint8_t> h_nchild;
+    std::vector<uint32_t> h_child_visits;
+    std::vector<double> h_value;
+};
+
+static std::string g_create_err;
+
+#define HIPCHK(e, call)                                                                      \
+    do {                                                                                     \
+        hipError_t _s = (call);                                                              \
+        if (_s != hipSuccess) {                                                              \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_s);                    \
+            return AZ_E_HIP;                                                                 \
+        }                                                                                    \
+    } while (0)
+
+template <typename T> static int dalloc(az_engine *e, T **out, size_t count) {
+    void *ptr = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    hipError_t s = hipMalloc(&ptr, bytes);
+    if (s != hipSuccess) {
+        e->err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(s);
+        return AZ_E_NOMEM;
+    }
+    e->dev_allocs.push_back(ptr);
+    e->sizes.device_bytes += (int64_t)bytes;
+    *out = (T *)ptr;
+    return AZ_OK;
+}
+
+static void pw_build(PwPlan &pw, int lo, int n) { // numpy pairwise_sum recursion (PW_BLOCKSIZE 128)
+    if (n <= 128) {
+        pw.lo[pw.n_blocks] = lo;
+        pw.len[pw.n_blocks] = n;
+        pw.ops[pw.n_ops++] = pw.n_blocks++;
+        return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    pw_build(pw, lo, n2);
+    pw_build(pw, lo + n2, n - n2);
+    pw.ops[pw.n_ops++] = -1;
+}
+
+extern "C" const char *az_last_error(const az_engine *e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int az_engine_destroy(az_engine *e) {
+    if (!e) return AZ_OK;
+    (void)hipSetDevice(e->cfg.device);
+    for (void *ptr : e->dev_allocs) (void)hipFree(ptr);
+    if (e->d_etas) (void)hipFree(e->d_etas);
+    if (e->d_us) (void)hipFree(e->d_us);
+    if (e->d_actions) (void)hipFree(e->d_actions);
+    delete e;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
+    if (!cfg || !out) {
+        g_create_err = "null argument";
+        return AZ_E_INVALID;
+    }
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(az_config)) {
+        g_create_err = "az_config.struct_size mismatch (header/library skew)";
+        return AZ_E_INVALID;
+    }
+    az_config c = *cfg;
+    if (c.game == AZ_GAME_CONNECT_FOUR) {
+        c.rows = 6;
+        c.cols = 7;
+    } else if (c.game == AZ_GAME_BREAKTHROUGH) {
+        if (c.rows < 4 || c.cols < 2 || c.rows * c.cols > 64 || 6 * c.cols > 64) {
+            g_create_err = "breakthrough board must satisfy rows>=4, rows*cols<=64, cols<=10";
+            return AZ_E_INVALID;
+        }
+    } else {
+        g_create_err = "unknown game id";
+        return AZ_E_INVALID;
+    }
+    if (c.n_slots < 1 || c.n_playouts < 1 || c.max_games < 1 || !(c.temperature > 0.0) || !(c.c_puct >= 0.0)) {
+        g_create_err = "n_slots, n_playouts, max_games must be >= 1; temperature > 0; c_puct >= 0";
+        return AZ_E_INVALID;
+    }
+    if (!c.use_dirichlet && c.n_playouts < 2) {
+        g_create_err = "n_playouts must be >= 2 without root Dirichlet expansion (mcts.py:162 divides by zero)";
+        return AZ_E_INVALID;
+    }
+    if (c.backup < 0 || c.backup > 3 || (c.rng_mode != AZ_RNG_PHILOX && c.rng_mode != AZ_RNG_INJECTED)) {
+        g_create_err = "bad backup / rng_mode";
+        return AZ_E_INVALID;
+    }
+    az_engine *e = new az_engine();
+    e->cfg = c;
+    memset(&e->p, 0, sizeof e->p);
+    memset(&e->sizes, 0, sizeof e->sizes);
+    hipError_t s = hipSetDevice(c.device);
+    if (s != hipSuccess) {
+        g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(s);
+        delete e;
+        return AZ_E_HIP;
+    }
+    Params &p = e->p;
+    p.geom = az_make_geom(c.game, c.rows, c.cols);
+    p.game = c.game;
+    p.A = az_num_actions(c.game, c.rows, c.cols);
+    p.maxc = az_max_children(c.game, c.rows, c.cols);
+    p.max_plies = az_max_plies(c.game, c.rows, c.cols);
+    p.obs_elems = 4 * c.rows * c.cols;
+    p.pstride = c.game == AZ_GAME_CONNECT_FOUR ? 64 : 192;
+    p.G = c.n_slots;
+    p.S = c.n_playouts;
+    p.use_dirichlet = c.use_dirichlet ? 1 : 0;
+    p.keep_tree = c.keep_search_tree ? 1 : 0;
+    p.backup = c.backup;
+    p.rng_mode = c.rng_mode;
+    p.max_sims_per_tick = c.max_sims_per_tick > 0 ? c.max_sims_per_tick : 32;
+    p.manual_moves = c.manual_moves ? 1 : 0;
+    p.need_per_move = (uint32_t)((c.n_playouts + 1) * p.maxc);
+    int64_t cap = c.nodes_per_slot > 0 ? c.nodes_per_slot : (int64_t)6 * p.need_per_move + 64;
+    if (cap < (int64_t)p.need_per_move + 2 || cap > 0x7FFFFFFFll) {
+        g_create_err = "nodes_per_slot too small for one search ((n_playouts+1)*max_children+2) or too large";
+        delete e;
+        return AZ_E_INVALID;
+    }
+    p.cap = (uint32_t)cap;
+    p.c_puct = c.c_puct;
+    p.one_minus_ratio = 1.0 - c.dirichlet_ratio;
+    p.alpha = c.dirichlet_alpha > 0 ? c.dirichlet_alpha : 0.3;
+    p.inv_temp = 1.0 / c.temperature;
+    p.seed = c.seed;
+    p.max_games = c.max_games;
+    if (c.game == AZ_GAME_CONNECT_FOUR) az_init_state<AZG_CONNECT_FOUR>(p.start, p.geom);
+    else az_init_state<AZG_BREAKTHROUGH>(p.start, p.geom);
+    pw_build(p.pw, 0, p.A);
+
+    az_sizes &z = e->sizes;
+    z.num_actions = p.A;
+    z.obs_planes = 4;
+    z.rows = c.rows;
+    z.cols = c.cols;
+    z.max_children = p.maxc;
+    z.max_plies = p.max_plies;
+    z.n_slots = p.G;
+    z.nodes_per_slot = cap;
+    z.max_games = c.max_games;
+
+    size_t nodes = (size_t)p.G * 2 * p.cap, G = (size_t)p.G;
+    size_t plies = (size_t)c.max_games * p.max_plies;
+    int rc = AZ_OK;
+#define DA(ptr, n) if (rc == AZ_OK) rc = dalloc(e, &(ptr), (n))
+    DA(p.N, nodes); DA(p.C0, nodes); DA(p.META, nodes); DA(p.Q, nodes); DA(p.P, nodes);
+    DA(p.phase, G); DA(p.gid, G); DA(p.ply, G); DA(p.sims, G); DA(p.which, G); DA(p.depth, G); DA(p.leaf_ply, G);
+    DA(p.root, G); DA(p.alloc, G); DA(p.leaf_node, G); DA(p.path, G * p.pstride);
+    DA(p.bb0, G); DA(p.bb1, G); DA(p.leaf_bb0, G); DA(p.leaf_bb1, G);
+    DA(p.stats, G * ST_N); DA(p.eta_buf, G * p.maxc);
+    DA(p.next_game, 1); DA(p.games_done, 1); DA(p.faults, 1);
+    DA(p.rec_len, (size_t)c.max_games); DA(p.rec_ret0, (size_t)c.max_games);
+    DA(p.rec_states, plies * 2); DA(p.rec_move, plies); DA(p.rec_nchild, plies);
+    DA(p.rec_child_action, plies * p.maxc); DA(p.rec_child_visits, plies * p.maxc); DA(p.rec_value, plies);
+#undef DA
+    if (rc != AZ_OK) {
+        g_create_err = e->err;
+        az_engine_destroy(e);
+        return rc;
+    }
+    (void)hipMemset(p.phase, 0, G * sizeof(int));
+    (void)hipMemset(p.path, 0, G * p.pstride * sizeof(uint32_t));
+    *out = e;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_sizes(const az_engine *e, az_sizes *out) {
+    if (!e || !out) return AZ_E_INVALID;
+    *out = e->sizes;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_reset(az_engine *e, uint64_t seed, int64_t n_games, void *stream) {
+    if (!e) return AZ_E_INVALID;
+    if (n_games < 1 || n_games > e->cfg.max_games) {
+        e->err = "n_games must be in [1, max_games]";
+        return AZ_E_INVALID;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    e->p.seed = seed;
+    e->p.n_games = n_games;
+    e->n_games = n_games;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(e, hipMemsetAsync(e->p.rec_len, 0, sizeof(int) * (size_t)e->cfg.max_games, st));
+    hipLaunchKernelGGL(az_reset_kernel, dim3((e->p.G + 255) / 256), dim3(256), 0, st, e->p);
+    HIPCHK(e, hipGetLastError());
+    e->reset_done = true;
+    e->ticks = 0;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_set_injected_rng(az_engine *e, const double *etas, const double *us, int64_t n_games) {
+    if (!e || !etas || !us || n_games < 1) return AZ_E_INVALID;
+    if (e->cfg.rng_mode != AZ_RNG_INJECTED) {
+        e->err = "engine was not created with rng_mode = AZ_RNG_INJECTED";
+        return AZ_E_STATE;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (e->d_etas) (void)hipFree(e->d_etas);
+    if (e->d_us) (void)hipFree(e->d_us);
+    e->d_etas = e->d_us = nullptr;
+    size_t ne = (size_t)n_games * e->p.max_plies * e->p.maxc, nu = (size_t)n_games * e->p.max_plies;
+    HIPCHK(e, hipMalloc((void **)&e->d_etas, ne * sizeof(double)));
+    HIPCHK(e, hipMalloc((void **)&e->d_us, nu * sizeof(double)));
+    HIPCHK(e, hipMemcpy(e->d_etas, etas, ne * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->d_us, us, nu * sizeof(double), hipMemcpyHostToDevice));
+    e->p.etas = e->d_etas;
+    e->p.us = e->d_us;
+    e->inj_games = n_games;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_set_start_prefix(az_engine *e, const int32_t *actions, int32_t n) {
+    if (!e || (n > 0 && !actions)) return AZ_E_INVALID;
+    AzState s;
+    float ret0 = 0.f;
+    int term = 0;
+    if (e->cfg.game == AZ_GAME_CONNECT_FOUR) {
+        az_init_state<AZG_CONNECT_FOUR>(s, e->p.geom);
+        for (int i = 0; i < n && !term; i++) {
+            if (actions[i] < 0 || actions[i] > 6 || !((az_c4_legal_mask(s) >> actions[i]) & 1u)) {
+                e->err = "illegal prefix action";
+                return AZ_E_INVALID;
+            }
+            term = az_apply<AZG_CONNECT_FOUR>(s, e->p.geom, actions[i], &ret0);
+        }
+    } else {
+        az_init_state<AZG_BREAKTHROUGH>(s, e->p.geom);
+        for (int i = 0; i < n && !term; i++) {
+            int a = actions[i];
+            if (a < 0 || a >= e->p.A) {
+                e->err = "illegal prefix action";
+                return AZ_E_INVALID;
+            }
+            int d = (a >> 1) % 6, cell = (a >> 1) / 6, me = s.ply & 1;
+            uint32_t mv = az_bt_cell_moves(s, e->p.geom, cell);
+            int dd = d - (me ? 3 : 0);
+            if (dd < 0 || dd > 2 || !(mv & (1u << dd)) || (int)((mv >> (4 + dd)) & 1u) != (a & 1)) {
+                e->err = "illegal prefix action";
+                return AZ_E_INVALID;
+            }
+            term = az_apply<AZG_BREAKTHROUGH>(s, e->p.geom, a, &ret0);
+        }
+    }
+    if (term) {
+        e->err = "prefix ends the game";
+        return AZ_E_INVALID;
+    }
+    e->p.start = s;
+    e->reset_done = false; // caller must reset again so that slots pick the new start up
+    return AZ_OK;
+}
+
+extern "C" int az_engine_advance(az_engine *e, const float *priors, const float *values, float *obs_out, void *stream) {
+    if (!e || !obs_out) return AZ_E_INVALID;
+    if (!e->reset_done) {
+        e->err = "az_engine_advance before az_engine_reset";
+        return AZ_E_STATE;
+    }
+    if (e->cfg.rng_mode == AZ_RNG_INJECTED && (!e->p.etas || e->inj_games < e->n_games)) {
+        e->err = "rng_mode INJECTED but az_engine_set_injected_rng was not called for all games";
+        return AZ_E_STATE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((e->p.G + 3) / 4), block(256);
+    bool pending = e->ticks > 0; // slots can only be waiting for the network after a first tick
+    if (pending && (!priors || !values)) {
+        e->err = "az_engine_advance: priors/values may be NULL only on the first tick after reset";
+        return AZ_E_INVALID;
+    }
+    if (e->cfg.game == AZ_GAME_CONNECT_FOUR) {
+        hipLaunchKernelGGL((az_advance_kernel<AZG_CONNECT_FOUR, 1>), grid, block, 0, st, e->p, priors, values, obs_out);
+        hipLaunchKernelGGL((az_move_kernel<AZG_CONNECT_FOUR>), grid, block, 0, st, e->p, obs_out);
+    } else {
+        hipLaunchKernelGGL((az_advance_kernel<AZG_BREAKTHROUGH, 3>), grid, block, 0, st, e->p, priors, values, obs_out);
+        hipLaunchKernelGGL((az_move_kernel<AZG_BREAKTHROUGH>), grid, block, 0, st, e->p, obs_out);
+    }
+    HIPCHK(e, hipGetLastError());
+    e->ticks++;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_update_root(az_engine *e, const int32_t *actions, int32_t keep_subtree, void *stream) {
+    if (!e || !actions) return AZ_E_INVALID;
+    if (!e->cfg.manual_moves) {
+        e->err = "az_engine_update_root needs an engine created with manual_moves = 1";
+        return AZ_E_STATE;
+    }
+    if (!e->reset_done) {
+        e->err = "az_engine_update_root before az_engine_reset";
+        return AZ_E_STATE;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!e->d_actions) HIPCHK(e, hipMalloc((void **)&e->d_actions, sizeof(int) * (size_t)e->p.G));
+    for (int g = 0; g < e->p.G; g++)
+        if (actions[g] >= e->p.A) {
+            e->err = "action out of range";
+            return AZ_E_INVALID;
+        }
+    HIPCHK(e, hipStreamSynchronize(st)); // the staging buffer is reused call to call
+    HIPCHK(e, hipMemcpy(e->d_actions, actions, sizeof(int) * (size_t)e->p.G, hipMemcpyHostToDevice));
+    dim3 grid((e->p.G + 3) / 4), block(256);
+    if (e->cfg.game == AZ_GAME_CONNECT_FOUR)
+        hipLaunchKernelGGL((az_update_root_kernel<AZG_CONNECT_FOUR>), grid, block, 0, st, e->p, e->d_actions, keep_subtree);
+    else
+        hipLaunchKernelGGL((az_update_root_kernel<AZG_BREAKTHROUGH>), grid, block, 0, st, e->p, e->d_actions, keep_subtree);
+    HIPCHK(e, hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_engine_progress(az_engine *e, az_progress *out, void *stream) {
+    if (!e || !out) return AZ_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    size_t G = (size_t)e->p.G;
+    std::vector<unsigned long long> stats(G * ST_N);
+    std::vector<int> phase(G);
+    unsigned long long next_game = 0, done = 0;
+    unsigned int faults = 0;
+    HIPCHK(e, hipStreamSynchronize(st));
+    HIPCHK(e, hipMemcpy(stats.data(), e->p.stats, stats.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(phase.data(), e->p.phase, G * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&next_game, e->p.next_game, sizeof next_game, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&done, e->p.games_done, sizeof done, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&faults, e->p.faults, sizeof faults, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    for (size_t g = 0; g < G; g++) {
+        const unsigned long long *s = &stats[g * ST_N];
+        out->moves += (int64_t)s[ST_MOVES];
+        out->sims += (int64_t)s[ST_SIMS];
+        out->evals += (int64_t)s[ST_EVALS];
+        out->terminal_hits += (int64_t)s[ST_TERM];
+        out->sum_depth += (int64_t)s[ST_DEPTH];
+        out->sum_children += (int64_t)s[ST_CHILDREN];
+        out->nodes_allocated += (int64_t)s[ST_NODES];
+        out->compactions += (int64_t)s[ST_COMPACT];
+        if (phase[g] == PH_WAIT_LEAF || phase[g] == PH_WAIT_ROOT) out->slots_waiting++;
+        if (phase[g] == PH_IDLE) out->slots_idle++;
+        if (phase[g] == PH_SEARCH_DONE) out->slots_search_done++;
+    }
+    out->games_started = (int64_t)(next_game < (unsigned long long)e->n_games ? next_game : (unsigned long long)e->n_games);
+    out->games_done = (int64_t)done;
+    out->error_flags = faults;
+    if (faults) {
+        e->err = "device fault flags set:";
+        if (faults & AZ_FAULT_POOL_EXHAUSTED) e->err += " POOL_EXHAUSTED";
+        if (faults & AZ_FAULT_PLY_OVERFLOW) e->err += " PLY_OVERFLOW";
+        if (faults & AZ_FAULT_NO_VISITS) e->err += " NO_VISITS";
+        if (faults & AZ_FAULT_BAD_PRIOR) e->err += " BAD_PRIOR";
+        return AZ_E_DEVICE;
+    }
+    return AZ_OK;
+}
+
+extern "C" int az_engine_export(az_engine *e, az_example_view *out, void *stream) {
+    if (!e || !out) return AZ_E_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    size_t ng = (size_t)e->n_games, mp = (size_t)e->p.max_plies, mc = (size_t)e->p.maxc;
+    e->h_len.resize(ng); e->h_ret0.resize(ng); e->h_states.resize(ng * mp * 2); e->h_move.resize(ng * mp);
+    e->h_nchild.resize(ng * mp); e->h_child_action.resize(ng * mp * mc); e->h_child_visits.resize(ng * mp * mc);
+    e->h_value.resize(ng * mp);
+    HIPCHK(e, hipMemcpy(e->h_len.data(), e->p.rec_len, ng * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(e->h_ret0.data(), e->p.rec_ret0, ng * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(e->h_states.data(), e->p.rec_states, ng * mp * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(e->h_move.data(), e->p.rec_move, ng * mp * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(e->h_nchild.data(), e->p.rec_nchild, ng * mp, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(e->h_child_action.data(), e->p.rec_child_action, ng * mp * mc * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(e->h_child_visits.data(), e->p.rec_child_visits, ng * mp * mc * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(e->h_value.data(), e->p.rec_value, ng * mp * sizeof(double), hipMemcpyDeviceToHost));
+    if (e->cfg.backup == AZ_BACKUP_ON_POLICY) // game_utils.py:200-204
+        for (size_t g = 0; g < ng; g++) {
+            double reward = (double)e->h_ret0[g];
+            if (e->p.start.ply & 1) reward = -reward; // first recorded ply is player 1's
+            for (int i = 0; i < e->h_len[g]; i++) {
+                e->h_value[g * mp + (size_t)e->p.start.ply + i] = reward;
+                reward *= -1;
+            }
+        }
+    out->n_games = (int64_t)ng;
+    out->max_plies = (int32_t)mp;
+    out->max_children = (int32_t)mc;
+    out->game_len = e->h_len.data();
+    out->game_ret0 = e->h_ret0.data();
+    out->states = e->h_states.data();
+    out->move = e->h_move.data();
+    out->n_children = e->h_nchild.data();
+    out->child_action = e->h_child_action.data();
+    out->child_visits = e->h_child_visits.data();
+    out->value = e->h_value.data();
+    return AZ_OK;
+}
+
+extern "C" int az_engine_read_slot(az_engine *e, int32_t slot, az_slot_info *o) {
+    if (!e || !o || slot < 0 || slot >= e->p.G) return AZ_E_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipDeviceSynchronize());
+#define RD(dst, src) HIPCHK(e, hipMemcpy(&(dst), (src) + slot, sizeof(dst), hipMemcpyDeviceToHost))
+    RD(o->phase, e->p.phase); RD(o->game_id, e->p.gid); RD(o->ply, e->p.ply); RD(o->sims_done, e->p.sims);
+    RD(o->root, e->p.root); RD(o->alloc, e->p.alloc); RD(o->bb[0], e->p.bb0); RD(o->bb[1], e->p.bb1);
+    RD(o->leaf_bb[0], e->p.leaf_bb0); RD(o->leaf_bb[1], e->p.leaf_bb1); RD(o->leaf_ply, e->p.leaf_ply);
+    RD(o->depth, e->p.depth);
+#undef RD
+    return AZ_OK;
+}
+
+extern "C" int az_engine_read_root(az_engine *e, int32_t slot, int64_t *root_n, double *root_q, int32_t *actions,
+                                   int64_t *child_n, double *child_q, double *child_p) {
+    if (!e || slot < 0 || slot >= e->p.G) return AZ_E_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipDeviceSynchronize());
+    int half = 0;
+    uint32_t root = 0, n = 0, c0 = 0, meta = 0;
+    HIPCHK(e, hipMemcpy(&half, e->p.which + slot, sizeof half, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&root, e->p.root + slot, sizeof root, hipMemcpyDeviceToHost));
+    size_t base = ((size_t)slot * 2 + half) * e->p.cap;
+    double q = 0;
+    HIPCHK(e, hipMemcpy(&n, e->p.N + base + root, 4, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&q, e->p.Q + base + root, 8, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&c0, e->p.C0 + base + root, 4, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&meta, e->p.META + base + root, 4, hipMemcpyDeviceToHost));
+    if (root_n) *root_n = n;
+    if (root_q) *root_q = q;
+    int nc = c0 == NONE32 ? 0 : (int)(meta >> 16);
+    if (nc > e->p.maxc) {
+        e->err = "corrupt root";
+        return AZ_E_DEVICE;
+    }
+    std::vector<uint32_t> N(nc), M(nc);
+    std::vector<double> Q(nc), P(nc);
+    if (nc) {
+        HIPCHK(e, hipMemcpy(N.data(), e->p.N + base + c0, 4 * nc, hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(M.data(), e->p.META + base + c0, 4 * nc, hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(Q.data(), e->p.Q + base + c0, 8 * nc, hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(P.data(), e->p.P + base + c0, 8 * nc, hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < nc; i++) {
+        if (actions) actions[i] = (int32_t)(M[i] & 0xFFFFu);
+        if (child_n) child_n[i] = N[i];
+        if (child_q) child_q[i] = Q[i];
+        if (child_p) child_p[i] = P[i];
+    }
+    return nc;
+}
+
+extern "C" int64_t az_engine_read_tree(az_engine *e, int32_t slot, int64_t max_nodes, int32_t *parent, int32_t *action,
+                                       int64_t *n, double *q, double *pp) {
+    if (!e || slot < 0 || slot >= e->p.G || max_nodes < 0) return AZ_E_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipDeviceSynchronize());
+    int half = 0;
+    uint32_t root = 0, alloc = 0;
+    HIPCHK(e, hipMemcpy(&half, e->p.which + slot, sizeof half, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&root, e->p.root + slot, sizeof root, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&alloc, e->p.alloc + slot, sizeof alloc, hipMemcpyDeviceToHost));
+    if (alloc > e->p.cap || root >= alloc) {
+        e->err = "corrupt slot";
+        return AZ_E_DEVICE;
+    }
+    size_t base = ((size_t)slot * 2 + half) * e->p.cap;
+    std::vector<uint32_t> N(alloc), C0(alloc), M(alloc);
+    std::vector<double> Q(alloc), P(alloc);
+    HIPCHK(e, hipMemcpy(N.data(), e->p.N + base, 4 * (size_t)alloc, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(C0.data(), e->p.C0 + base, 4 * (size_t)alloc, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(M.data(), e->p.META + base, 4 * (size_t)alloc, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(Q.data(), e->p.Q + base, 8 * (size_t)alloc, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(P.data(), e->p.P + base, 8 * (size_t)alloc, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> order;  // BFS queue of pool indices
+    std::vector<int32_t> par;
+    order.push_back(root);
+    par.push_back(-1);
+    for (size_t i = 0; i < order.size(); i++) {
+        uint32_t nd = order[i];
+        if (C0[nd] == NONE32) continue;
+        uint32_t nc = M[nd] >> 16;
+        if (C0[nd] + nc > alloc) {
+            e->err = "corrupt tree";
+            return AZ_E_DEVICE;
+        }
+        for (uint32_t k = 0; k < nc; k++) {
+            order.push_back(C0[nd] + k);
+            par.push_back((int32_t)i);
+        }
+    }
+    int64_t cnt = (int64_t)order.size(), w = cnt < max_nodes ? cnt : max_nodes;
+    for (int64_t i = 0; i < w; i++) {
+        uint32_t nd = order[(size_t)i];
+        if (parent) parent[i] = par[(size_t)i];
+        if (action) action[i] = i == 0 ? -1 : (int32_t)(M[nd] & 0xFFFFu);
+        if (n) n[i] = N[nd];
+        if (q) q[i] = Q[nd];
+        if (pp) pp[i] = P[nd];
+    }
+    return cnt;
+}

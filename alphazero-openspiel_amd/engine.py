@@ -1,0 +1,331 @@
+"""Python handle on the HIP self-play engine (C ABI: include/az_engine.h) + the tick loop.
+
+PyTorch is plumbing here: it owns the observation / prior / value device tensors, the stream and the
+PV-net; the search, game dynamics and rollout loop are the HIP kernels in csrc/az_engine.hip.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .games import Game, boards_from_bitboards
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _device_index(device):
+    if isinstance(device, int):
+        return device
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise EngineError("the self-play engine runs on a HIP device only (got %s); there is no CPU path" % device)
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+class SelfPlayEngine:
+    """G concurrent games of AlphaZero self-play on one GPU.
+
+    Keyword names follow the reference's kwargs (mcts.py:96-101, alphazerobot.py:26,34-38,
+    game_utils.py:155): n_playouts, c_puct, use_dirichlet, dirichlet_ratio, temperature,
+    keep_search_tree, backup."""
+
+    def __init__(self, game_name, n_slots, n_playouts=100, c_puct=2.5, temperature=1.0, dirichlet_ratio=0.25,
+                 use_dirichlet=True, keep_search_tree=True, backup="on-policy", max_games=None, device=0,
+                 rng="philox", seed=0, nodes_per_slot=0, max_sims_per_tick=0, manual_moves=False,
+                 dirichlet_alpha=0.3):
+        self.lib = _lib.load()
+        self.game = Game(game_name) if isinstance(game_name, str) else game_name
+        self.device_index = _device_index(device)
+        self.device = torch.device("cuda", self.device_index)
+        if backup not in _lib.BACKUPS:
+            raise ValueError("backup must be one of %s" % sorted(_lib.BACKUPS))
+        cfg = _lib.AzConfig()
+        cfg.struct_size = C.sizeof(_lib.AzConfig)
+        cfg.game, cfg.rows, cfg.cols = self.game.game_id, self.game.rows, self.game.cols
+        cfg.n_slots = int(n_slots)
+        cfg.n_playouts = int(n_playouts)
+        cfg.use_dirichlet = int(bool(use_dirichlet))
+        cfg.keep_search_tree = int(bool(keep_search_tree))
+        cfg.backup = _lib.BACKUPS[backup]
+        cfg.rng_mode = {"philox": _lib.RNG_PHILOX, "injected": _lib.RNG_INJECTED}[rng]
+        cfg.max_sims_per_tick = int(max_sims_per_tick)
+        cfg.device = self.device_index
+        cfg.manual_moves = int(bool(manual_moves))
+        cfg.nodes_per_slot = int(nodes_per_slot)
+        cfg.max_games = int(max_games if max_games is not None else n_slots)
+        cfg.c_puct = float(c_puct)
+        cfg.dirichlet_ratio = float(dirichlet_ratio)
+        cfg.dirichlet_alpha = float(dirichlet_alpha)
+        cfg.temperature = float(temperature)
+        cfg.seed = int(seed) & (2 ** 64 - 1)
+        self.cfg = cfg
+        self.backup = backup
+        self._h = C.c_void_p()
+        rc = self.lib.az_engine_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise EngineError("az_engine_create failed (%d): %s" % (rc, self.lib.az_last_error(None).decode()))
+        z = _lib.AzSizes()
+        self._check(self.lib.az_engine_sizes(self._h, C.byref(z)))
+        self.sizes = z
+        self.G, self.A = z.n_slots, z.num_actions
+        self.obs_shape = (z.obs_planes, z.rows, z.cols)
+        self.max_plies, self.max_children = z.max_plies, z.max_children
+        self.start_history = []
+        self.n_games = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc < 0:
+            raise EngineError("engine call failed (%d): %s" % (rc, self.lib.az_last_error(self._h).decode()))
+        return rc
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.az_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc_io(self):
+        """(obs[G,C+1,H,W], priors[G,A], values[G]) float32 device tensors of the right shape."""
+        obs = torch.zeros((self.G,) + self.obs_shape, dtype=torch.float32, device=self.device)
+        pri = torch.full((self.G, self.A), 1.0 / self.A, dtype=torch.float32, device=self.device)
+        val = torch.zeros((self.G,), dtype=torch.float32, device=self.device)
+        return obs, pri, val
+
+    # ------------------------------------------------------------------ C ABI
+    def reset(self, n_games, seed=None):
+        if seed is None:
+            seed = self.cfg.seed
+        self._check(self.lib.az_engine_reset(self._h, int(seed) & (2 ** 64 - 1), int(n_games), self._stream()))
+        self.n_games = int(n_games)
+
+    def set_start_prefix(self, actions):
+        arr = (C.c_int32 * max(1, len(actions)))(*[int(a) for a in actions])
+        self._check(self.lib.az_engine_set_start_prefix(self._h, arr, len(actions)))
+        self.start_history = [int(a) for a in actions]
+
+    def set_injected_rng(self, etas, us):
+        """etas: per game, per ply, the Dirichlet draw (ragged lists ok); us: per game, per ply uniforms."""
+        n = len(us)
+        e = np.zeros((n, self.max_plies, self.max_children), dtype=np.float64)
+        u = np.zeros((n, self.max_plies), dtype=np.float64)
+        off = len(self.start_history)
+        for g in range(n):
+            for i, row in enumerate(etas[g] if etas is not None else []):
+                e[g, off + i, :len(row)] = row
+            u[g, off:off + len(us[g])] = us[g]
+        dp = C.POINTER(C.c_double)
+        self._check(self.lib.az_engine_set_injected_rng(self._h, e.ctypes.data_as(dp), u.ctypes.data_as(dp), n))
+
+    def _ptr(self, t, shape):
+        if t is None:
+            return None
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device or tuple(t.shape) != shape:
+            raise EngineError("expected a contiguous float32 %s tensor on %s, got %s %s on %s"
+                              % (shape, self.device, t.dtype, tuple(t.shape), t.device))
+        return C.c_void_p(t.data_ptr())
+
+    def advance(self, priors, values, obs):
+        """One tick: consume (priors, values) for last tick's requests, search on, write new requests to obs."""
+        self._check(self.lib.az_engine_advance(self._h, self._ptr(priors, (self.G, self.A)),
+                                               self._ptr(values, (self.G,)),
+                                               self._ptr(obs, (self.G,) + self.obs_shape), self._stream()))
+
+    def update_root(self, actions, keep_subtree=True):
+        arr = (C.c_int32 * self.G)(*[int(a) for a in actions])
+        self._check(self.lib.az_engine_update_root(self._h, arr, int(bool(keep_subtree)), self._stream()))
+
+    def progress(self, check=True):
+        p = _lib.AzProgress()
+        rc = self.lib.az_engine_progress(self._h, C.byref(p), self._stream())
+        if check:
+            self._check(rc)
+        return {name: getattr(p, name) for name, _ in _lib.AzProgress._fields_ if name != "reserved"}
+
+    def read_root(self, slot):
+        mc = self.max_children
+        rn, rq = C.c_int64(), C.c_double()
+        acts, cn = (C.c_int32 * mc)(), (C.c_int64 * mc)()
+        cq, cp = (C.c_double * mc)(), (C.c_double * mc)()
+        n = self._check(self.lib.az_engine_read_root(self._h, slot, C.byref(rn), C.byref(rq), acts, cn, cq, cp))
+        return {"N": rn.value, "Q": rq.value, "actions": list(acts[:n]), "cN": list(cn[:n]),
+                "cQ": list(cq[:n]), "cP": list(cp[:n])}
+
+    def read_slot(self, slot):
+        s = _lib.AzSlotInfo()
+        self._check(self.lib.az_engine_read_slot(self._h, slot, C.byref(s)))
+        return {"phase": s.phase, "game_id": s.game_id, "ply": s.ply, "sims_done": s.sims_done, "root": s.root,
+                "alloc": s.alloc, "bb": [s.bb[0], s.bb[1]], "leaf_bb": [s.leaf_bb[0], s.leaf_bb[1]],
+                "leaf_ply": s.leaf_ply, "depth": s.depth}
+
+    def read_tree(self, slot):
+        """Whole tree of a slot, breadth-first: dict of numpy arrays parent/action/N/Q/P."""
+        n = self._check(self.lib.az_engine_read_tree(self._h, slot, 0, None, None, None, None, None))
+        par, act = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        N, Q, P = np.zeros(n, np.int64), np.zeros(n, np.float64), np.zeros(n, np.float64)
+        ip, lp, dp = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+        self._check(self.lib.az_engine_read_tree(self._h, slot, n, par.ctypes.data_as(ip), act.ctypes.data_as(ip),
+                                                 N.ctypes.data_as(lp), Q.ctypes.data_as(dp), P.ctypes.data_as(dp)))
+        return {"parent": par, "action": act, "N": N, "Q": Q, "P": P}
+
+    def export(self):
+        """Finished games as numpy arrays (copies)."""
+        v = _lib.AzExampleView()
+        self._check(self.lib.az_engine_export(self._h, C.byref(v), self._stream()))
+        n, mp, mc = v.n_games, v.max_plies, v.max_children
+
+        def arr(ptr, shape, dtype):
+            cnt = int(np.prod(shape))
+            return np.ctypeslib.as_array(ptr, shape=(cnt,)).view(dtype).reshape(shape).copy()
+
+        return {
+            "game_len": arr(v.game_len, (n,), np.int32), "game_ret0": arr(v.game_ret0, (n,), np.float32),
+            "states": arr(v.states, (n, mp, 2), np.uint64), "move": arr(v.move, (n, mp), np.uint16),
+            "n_children": arr(v.n_children, (n, mp), np.uint8),
+            "child_action": arr(v.child_action, (n, mp, mc), np.uint16),
+            "child_visits": arr(v.child_visits, (n, mp, mc), np.uint32),
+            "value": arr(v.value, (n, mp), np.float64),
+            "start_ply": len(self.start_history),
+        }
+
+
+# ---------------------------------------------------------------------- host logic on engine records
+def pi_from_visits(actions, visits, num_actions):
+    """MCTS.get_normalized_visit_counts + remove_illegal_actions (mcts.py:155-162, alphazerobot.py:7-18)
+    from the recorded root child visit counts, with numpy's own arithmetic -> list[A] of python floats."""
+    total = int(np.sum(visits.astype(np.int64)))
+    nv = np.zeros(num_actions, dtype=np.float64)
+    nv[actions] = visits.astype(np.float64) / float(total)
+    s = np.sum(nv)
+    if s > 1e-6:
+        nv = nv / s
+    else:
+        nv = np.zeros(num_actions)
+        nv[actions] = 1.0 / len(actions)
+    return nv.tolist()
+
+
+def examples_from_export(game, ex, start_history=()):
+    """Engine records -> the reference's list of games, each a list of `[info_state_str, board (C+1,H,W)
+    float64, pi list[A], value]` (game_utils.py:169,200-204; consumed by train.py:109-126,172-198)."""
+    A = game.num_distinct_actions()
+    games = []
+    p0 = int(ex["start_ply"])
+    prefix = [int(a) for a in start_history]
+    for g in range(len(ex["game_len"])):
+        n = int(ex["game_len"][g])
+        sl = slice(p0, p0 + n)
+        boards = boards_from_bitboards(game, ex["states"][g, sl], np.arange(p0, p0 + n))
+        moves = ex["move"][g, sl].tolist()
+        plies = []
+        for i in range(n):
+            nc = int(ex["n_children"][g, p0 + i])
+            pi = pi_from_visits(ex["child_action"][g, p0 + i, :nc].astype(np.int64),
+                                ex["child_visits"][g, p0 + i, :nc], A)
+            key = ", ".join(str(a) for a in prefix + moves[:i])
+            plies.append([key, boards[i], pi, float(ex["value"][g, p0 + i])])
+        games.append(plies)
+    return games
+
+
+# ---------------------------------------------------------------------- evaluation of the request batch
+class DeviceEvaluator:
+    """The engine-side replacement of Evaluator + handle_gpu (examplegenerator.py:39-77): one
+    `net.forward` over the whole device-resident request batch, no pipes, no host copies.
+    dtype: torch.float32 (reference arithmetic) or torch.float16 / torch.bfloat16 autocast."""
+
+    def __init__(self, net, device, dtype=torch.float32, channels_last=False):
+        self.net = net.to(device).eval()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.channels_last = channels_last
+        if channels_last:
+            self.net = self.net.to(memory_format=torch.channels_last)
+
+    @torch.no_grad()
+    def __call__(self, obs, priors_out, values_out):
+        x = obs.contiguous(memory_format=torch.channels_last) if self.channels_last else obs
+        if self.dtype == torch.float32:
+            p, v = self.net(x)
+        else:
+            with torch.autocast("cuda", dtype=self.dtype):
+                p, v = self.net(x)
+        priors_out.copy_(p)
+        values_out.copy_(v.reshape(-1))
+
+
+class HostPolicyEvaluator:
+    """Routes requests through a reference-style `policy_fn(state) -> (priors, value)` on the host
+    (Evaluator.evaluate_nn's contract, examplegenerator.py:44-54).  Slow by construction — it exists for
+    parity tests and for AlphaZeroBot(policy_fn=<python callable>)."""
+
+    def __init__(self, engine, board_fn):
+        """board_fn(board float64 (C+1,H,W)) -> (priors[A], value)"""
+        self.engine = engine
+        self.board_fn = board_fn
+
+    def __call__(self, obs, priors_out, values_out):
+        e = self.engine
+        boards = obs.detach().cpu().numpy().astype(np.float64)
+        pri = np.empty((e.G, e.A), dtype=np.float32)
+        val = np.empty((e.G,), dtype=np.float32)
+        for g in range(e.G):
+            p, v = self.board_fn(boards[g])
+            pri[g] = np.asarray(p, dtype=np.float32)
+            val[g] = np.float32(v)
+        priors_out.copy_(torch.from_numpy(pri))
+        values_out.copy_(torch.from_numpy(val))
+
+
+def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_ticks=None, use_graph=False,
+                 on_tick=None):
+    """ExampleGenerator.run_games without processes: tick the engine until n_games are finished.
+    Returns the final progress dict."""
+    engine.reset(n_games, seed)
+    obs, pri, val = engine.alloc_io()
+    ticks = 0
+    graph = None
+    if use_graph:
+        # one tick = [az_advance_kernel, az_move_kernel, net.forward] replayed as a HIP graph
+        torch.cuda.synchronize(engine.device)
+        side = torch.cuda.Stream(engine.device)
+        side.wait_stream(torch.cuda.current_stream(engine.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up (MIOpen / workspace allocation must happen outside capture)
+                engine.advance(pri, val, obs)
+                evaluator(obs, pri, val)
+                ticks += 1
+        torch.cuda.current_stream(engine.device).wait_stream(side)
+        torch.cuda.synchronize(engine.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            engine.advance(pri, val, obs)
+            evaluator(obs, pri, val)
+    while True:
+        for _ in range(check_every):
+            if graph is not None:
+                graph.replay()
+            else:
+                engine.advance(pri, val, obs)
+                evaluator(obs, pri, val)
+            ticks += 1
+            if on_tick is not None:
+                on_tick(engine, ticks)
+        prog = engine.progress()
+        if prog["games_done"] >= n_games:
+            break
+        if max_ticks is not None and ticks >= max_ticks:
+            raise EngineError("self-play did not finish within %d ticks: %r" % (max_ticks, prog))
+    prog["ticks"] = ticks
+    return prog

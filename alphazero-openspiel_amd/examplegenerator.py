@@ -1,0 +1,75 @@
+"""`ExampleGenerator` with the reference's signature (examplegenerator.py:80-175), on the HIP engine.
+
+Reference: `n_pools` pools, each = one busy-polling `handle_gpu` process + `n_processes` worker
+processes playing one game at a time, a pickled batch-1 board per leaf over a Pipe
+(examplegenerator.py:39-77,106-138).  Here: one process per GPU, all games of the shard resident on
+the device as engine slots, one `net.forward` per tick over every outstanding leaf; across GPUs the
+games shard over `torch.distributed` ranks and the examples are all-gathered once at generation end
+(RCCL over xGMI; nothing is exchanged during the search).
+"""
+import copy
+
+import numpy as np
+import torch
+
+from .engine import DeviceEvaluator, EngineError, SelfPlayEngine, examples_from_export, run_selfplay
+from .games import Game
+from . import distributed as azdist
+
+_ENGINE_KW = ("n_playouts", "c_puct", "temperature", "dirichlet_ratio", "use_dirichlet", "keep_search_tree",
+              "backup")
+
+
+class ExampleGenerator:
+    def __init__(self, net, game_name, device, n_pools=1, n_processes=1, **kwargs):
+        if kwargs.get("is_test") or kwargs.get("net2") is not None:
+            raise NotImplementedError("the evaluation-arena branches (is_test / net2 / generate_tests, "
+                                      "reference examplegenerator.py:88-90,100-103,177-195) are outside the "
+                                      "self-play hot path this package replaces")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise EngineError("ExampleGenerator needs a HIP device: self-play runs in HIP kernels, there is no "
+                              "CPU fallback (got device=%s)" % (device,))
+        self.net = copy.deepcopy(net)  # examplegenerator.py:86: a frozen copy of the current net
+        self.game_name = game_name
+        self.game = Game(game_name)
+        self.n_pools, self.n_processes = n_pools, n_processes  # accepted for signature parity; see module doc
+        self.kwargs = kwargs
+        # engine extensions (not reference keywords)
+        self.n_slots = kwargs.get("n_slots")           # concurrent games per GPU; default min(n_games, 4096)
+        self.seed = int(kwargs.get("seed", np.random.randint(0, 2 ** 31 - 1)))
+        self.eval_dtype = kwargs.get("eval_dtype", torch.float32)
+        self.use_graph = bool(kwargs.get("use_graph", True))
+        self.last_progress = None
+        self._generation = 0
+
+    def _engine_kwargs(self):
+        return {k: self.kwargs[k] for k in _ENGINE_KW if k in self.kwargs}
+
+    def generate_examples(self, n_games):
+        """-> list of games; a game is a list of [info_state_str, board (C+1,H,W) f64, pi list[A], z]
+        (examplegenerator.py:164-175, game_utils.py:169,200-204).  With torch.distributed initialised each rank
+        plays int(n_games / world_size) games (remainder dropped like int(n_games / n_pools),
+        examplegenerator.py:149) and every rank returns the gathered list."""
+        world, rank = azdist.world_size(), azdist.rank()
+        n_local = int(n_games / world)
+        if n_local < 1:
+            raise ValueError("n_games=%d is fewer than the %d ranks" % (n_games, world))
+        n_slots = int(self.n_slots or min(n_local, 4096))
+        engine = SelfPlayEngine(self.game, n_slots, max_games=n_local, device=self.device,
+                                seed=self.seed + 1000003 * self._generation + 7919 * rank, **self._engine_kwargs())
+        try:
+            evaluator = DeviceEvaluator(self.net, self.device, dtype=self.eval_dtype)
+            self.last_progress = run_selfplay(engine, evaluator, n_local, use_graph=self.use_graph)
+            packed = azdist.pack_export(engine.export())
+        finally:
+            engine.close()
+        self._generation += 1
+        exports = azdist.all_gather_exports(packed, self.device)
+        games = []
+        for ex in exports:
+            games.extend(examples_from_export(self.game, ex))
+        return games
+
+    def generate_tests(self, n_games, game_fn, n_playouts_mcts):
+        raise NotImplementedError("evaluation arenas are outside the self-play hot path (see __init__)")

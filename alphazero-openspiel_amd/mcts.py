@@ -1,0 +1,182 @@
+"""`MCTS` / `Node` with the reference's interface (mcts.py:10-223), backed by ONE engine slot on the GPU.
+
+`MCTS(policy_fn, A, **kw).search(state)` runs the S sequential playouts of mcts.py:164-180 in the HIP
+kernels (manual_moves engine, G = 1) and returns the normalised root visit counts.  `update_root`
+maps to az_engine_update_root, `root` is a read-only Node view rebuilt from az_engine_read_tree.
+
+Randomness: the root Dirichlet vector is drawn HERE with `np.random.dirichlet(0.3 * ones(n_legal))`
+from numpy's global stream, exactly where the reference draws it (mcts.py:187), and injected into
+the engine — so after `np.random.seed(k)` a façade game consumes the same random numbers as a
+reference game.
+
+policy_fn: a bound `Net.predict` / an nn.Module (evaluated on the device) or any python
+`policy_fn(state) -> (priors[A], value)` (evaluated on the host per leaf; slow, for parity/debug).
+"""
+import numpy as np
+import torch
+
+from .engine import DeviceEvaluator, SelfPlayEngine
+from .games import Game, State
+
+
+class Node:
+    """Read-only snapshot of a tree node: parent, children {action: Node}, P, Q, N (mcts.py:10-20)."""
+
+    def __init__(self, parent, prior_p, use_puct=True):
+        self.parent = parent
+        self.children = dict()
+        self.P = prior_p
+        self.Q = 0
+        self.N = 0
+        self.use_puct = use_puct
+
+    def is_leaf(self):
+        return self.children == {}
+
+    def is_root(self):
+        return self.parent is None
+
+
+def _tree_to_nodes(tree):
+    nodes = []
+    for i in range(len(tree["N"])):
+        par = nodes[tree["parent"][i]] if i else None
+        nd = Node(par, float(tree["P"][i]))
+        nd.N, nd.Q = int(tree["N"][i]), float(tree["Q"][i])
+        if par is not None:
+            par.children[int(tree["action"][i])] = nd
+        nodes.append(nd)
+    if nodes[0].N == 0:
+        nodes[0].Q = 0
+    return nodes[0]
+
+
+def _as_module(policy_fn):
+    if isinstance(policy_fn, torch.nn.Module):
+        return policy_fn
+    owner = getattr(policy_fn, "__self__", None)
+    if isinstance(owner, torch.nn.Module) and getattr(policy_fn, "__name__", "") == "predict":
+        return owner
+    return None
+
+
+class MCTS:
+    def __init__(self, policy_fn, num_distinct_actions, c_puct=2.5, n_playouts=100, use_dirichlet=True,
+                 dirichlet_ratio=0.25, use_puct=True, **kwargs):
+        if not use_puct:
+            raise NotImplementedError("only the PUCT rule (mcts.py:78) is built; the UCT variant (mcts.py:80) is "
+                                      "outside the self-play path")
+        self.num_distinct_actions = num_distinct_actions
+        self.c_puct, self.n_playouts = c_puct, n_playouts
+        self.use_dirichlet, self.dirichlet_ratio, self.use_puct = use_dirichlet, dirichlet_ratio, use_puct
+        self.policy_fn = policy_fn
+        self.device = kwargs.get("device", None)
+        self._engine = None
+        self._history = None  # action history of the engine's root state
+        self._io = None
+        self._evaluator = None
+        self.n_evals = 0
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _ensure_engine(self, state):
+        if self._engine is not None:
+            return
+        game = state.get_game() if hasattr(state, "get_game") else state._game
+        if not isinstance(game, Game):
+            game = Game(str(game))
+        dev = self.device
+        if dev is None:
+            mod = _as_module(self.policy_fn)
+            dev = next(mod.parameters()).device if mod is not None else torch.device("cuda", torch.cuda.current_device())
+        self._game = game
+        self._engine = SelfPlayEngine(game, 1, n_playouts=self.n_playouts, c_puct=self.c_puct,
+                                      use_dirichlet=self.use_dirichlet, dirichlet_ratio=self.dirichlet_ratio,
+                                      keep_search_tree=True, manual_moves=True, rng="injected", device=dev,
+                                      max_games=1, max_sims_per_tick=max(32, self.n_playouts))
+        self._io = self._engine.alloc_io()
+        mod = _as_module(self.policy_fn)
+        self._evaluator = DeviceEvaluator(mod, self._engine.device) if mod is not None else None
+
+    def _restart(self, history):
+        e = self._engine
+        e.set_start_prefix(history)
+        e.reset(1)
+        self._history = list(history)
+
+    def _sync_root(self, state):
+        hist = [int(a) for a in state.history()]
+        if self._history is None or hist[:len(self._history)] != self._history or len(hist) > len(self._history) + 2:
+            self._restart(hist)
+            return
+        for a in hist[len(self._history):]:
+            self.update_root(a)
+
+    def _host_eval(self, obs, pri, val):
+        e = self._engine
+        info = e.read_slot(0)
+        waiting_root = info["phase"] == 3
+        st = State(self._game)
+        st.bb = list(info["bb"] if waiting_root else info["leaf_bb"])
+        ply = info["ply"] if waiting_root else info["leaf_ply"]
+        st._hist = list(self._history) + [-1] * (ply - len(self._history))  # path actions are not tracked
+        p, v = self.policy_fn(st)
+        pri.copy_(torch.tensor(np.asarray(p, dtype=np.float32)).reshape(1, -1))
+        val.fill_(float(v))
+
+    # ------------------------------------------------------------------ reference interface
+    def search(self, state):
+        self._ensure_engine(state)
+        self._sync_root(state)
+        e = self._engine
+        obs, pri, val = self._io
+        ply = len(self._history)
+        if self.use_dirichlet:  # the draw of mcts.py:187, from numpy's global stream
+            n_legal = len(state.legal_actions(state.current_player()))
+            eta = np.random.dirichlet(0.3 * np.ones(n_legal))
+            e.start_history = []
+            e.set_injected_rng([[[0.0]] * ply + [list(eta)]], [[0.0] * (ply + 1)])
+        else:
+            e.start_history = []
+            e.set_injected_rng(None, [[0.0] * (ply + 1)])
+        for _ in range(4 * self.n_playouts + 16):
+            e.advance(pri, val, obs)
+            info = e.read_slot(0)
+            if info["phase"] == 5:  # search done
+                break
+            if info["phase"] in (3, 4):
+                self.n_evals += 1
+                if self._evaluator is not None:
+                    self._evaluator(obs, pri, val)
+                else:
+                    self._host_eval(obs, pri, val)
+        else:
+            raise RuntimeError("search did not finish: %r" % (e.progress(),))
+        e.progress()  # raises on device faults
+        return self.get_normalized_visit_counts()
+
+    def get_normalized_visit_counts(self):
+        r = self._engine.read_root(0)
+        visits = [0] * self.num_distinct_actions
+        for a, n in zip(r["actions"], r["cN"]):
+            visits[a] = n
+        total = sum(visits)
+        return [float(v) / total for v in visits]
+
+    def update_root(self, action):
+        if self._engine is None:
+            return
+        e = self._engine
+        info = e.read_slot(0)
+        if info["phase"] == 0:  # idle slot (terminal position reached): restart lazily on the next search
+            self._history = None
+            return
+        e.update_root([int(action)], keep_subtree=True)
+        self._history.append(int(action))
+        if e.read_slot(0)["phase"] == 0:
+            self._history = None
+
+    @property
+    def root(self):
+        if self._engine is None:
+            return Node(None, 0.0)
+        return _tree_to_nodes(self._engine.read_tree(0))

@@ -1,0 +1,212 @@
+/*
+ * az_engine.h — C ABI of the MI355X-native AlphaZero self-play engine.
+ *
+ * This is the drop-in boundary for ONE path of danielwillemsen/alphazero-openspiel:
+ * PUCT tree search (mcts.py) + self-play rollout loop (game_utils.py:148-206) +
+ * agent step (alphazerobot.py:42-93) + game dynamics / state encoding
+ * (pyspiel calls, network.py:9-18), run for G concurrent games on one GPU.
+ * Leaf evaluation (network.py:48-64) is the caller's: the engine hands out a
+ * device batch of observations and takes back device priors/values, so the
+ * reference's multiprocess pipe protocol (examplegenerator.py:39-77) has no
+ * equivalent here — its two messages are the two pointer arguments of
+ * az_engine_advance().
+ *
+ * Conventions: every entry returns 0 on success, a negative AZ_E_* otherwise;
+ * no C++ exception crosses this boundary; az_last_error() gives the text.
+ * "dev" pointers are HIP device pointers owned by the caller; `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).  All device work is
+ * asynchronous on that stream unless a function says it synchronises.
+ * The engine is not re-entrant: one host thread per engine, one engine (or
+ * more) per GPU, one process per GPU.
+ */
+#ifndef AZ_ENGINE_H
+#define AZ_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZ_GAME_CONNECT_FOUR 0 /* "connect_four"                      (train.py:24) */
+#define AZ_GAME_BREAKTHROUGH 1 /* "breakthrough(rows=R,columns=C)"    (train.py:24, tournament.py) */
+
+/* value-target modes of play_game_self (game_utils.py:166-194) */
+#define AZ_BACKUP_ON_POLICY 0
+#define AZ_BACKUP_SOFT_Z 1
+#define AZ_BACKUP_A0C 2
+#define AZ_BACKUP_OFF_POLICY 3
+
+#define AZ_RNG_PHILOX 0   /* on-device Philox4x32-10 streams keyed by (seed, game id, ply) */
+#define AZ_RNG_INJECTED 1 /* Dirichlet vectors and choice-uniforms supplied by the caller (parity mode) */
+
+#define AZ_OK 0
+#define AZ_E_INVALID (-1)   /* bad argument / config */
+#define AZ_E_HIP (-2)       /* a HIP runtime call failed */
+#define AZ_E_STATE (-3)     /* call order violated (e.g. advance before reset) */
+#define AZ_E_DEVICE (-4)    /* a device-side fault flag is set (see az_progress.error_flags) */
+#define AZ_E_NOMEM (-5)
+
+/* device-side fault bits, OR-ed into az_progress.error_flags */
+#define AZ_FAULT_POOL_EXHAUSTED 1u /* a slot's node pool is full even after compaction */
+#define AZ_FAULT_PLY_OVERFLOW 2u   /* a game exceeded max_plies */
+#define AZ_FAULT_NO_VISITS 4u      /* root has no visited child at move time (S too small) */
+#define AZ_FAULT_BAD_PRIOR 8u      /* NaN prior/value fed to advance */
+
+/*
+ * Search/agent configuration.  Field ↔ reference keyword (all reach the
+ * reference's search as **kwargs: SURVEY.md §5 "Config / flag system"):
+ *   n_playouts, c_puct, use_dirichlet, dirichlet_ratio   mcts.py:96-101
+ *   temperature                                          alphazerobot.py:38
+ *   keep_search_tree                                     alphazerobot.py:26,54-68
+ *   backup                                               game_utils.py:155
+ * dirichlet_alpha is the literal 0.3 of mcts.py:187; the noise weight is the
+ * literal 0.25 of mcts.py:189 (NOT dirichlet_ratio) — reproduced as such.
+ */
+typedef struct az_config {
+    int32_t struct_size; /* = sizeof(az_config); ABI guard */
+    int32_t game;        /* AZ_GAME_* */
+    int32_t rows, cols;  /* breakthrough board (connect_four: 6,7 enforced) */
+    int32_t n_slots;     /* G: concurrent games resident on the device */
+    int32_t n_playouts;  /* S */
+    int32_t use_dirichlet;
+    int32_t keep_search_tree;
+    int32_t backup;            /* AZ_BACKUP_* */
+    int32_t rng_mode;          /* AZ_RNG_* */
+    int32_t max_sims_per_tick; /* bound on NN-free playouts (terminal hits) one slot runs per advance; 0 = default */
+    int32_t device;            /* HIP device ordinal */
+    int32_t manual_moves;      /* 1: stop after each search (MCTS.search semantics); the caller reads the root and
+                                  moves with az_engine_update_root — AlphaZeroBot.step outside self-play */
+    int32_t reserved0;
+    int64_t nodes_per_slot;    /* node-pool capacity per slot; 0 = default from game and S */
+    int64_t max_games;         /* capacity of the example store (games per reset) */
+    double c_puct;
+    double dirichlet_ratio;
+    double dirichlet_alpha;
+    double temperature;
+    uint64_t seed;
+} az_config;
+
+typedef struct az_sizes {
+    int32_t num_actions;  /* A   = game.num_distinct_actions() */
+    int32_t obs_planes;   /* C+1 = state_shape[0] + 1 (network.py:15) */
+    int32_t rows, cols;   /* H, W */
+    int32_t max_children; /* upper bound on legal actions of any state */
+    int32_t max_plies;    /* upper bound on game length */
+    int32_t n_slots;
+    int32_t reserved;
+    int64_t nodes_per_slot;
+    int64_t max_games;
+    int64_t device_bytes; /* HBM held by the engine */
+} az_sizes;
+
+typedef struct az_progress {
+    int64_t games_started, games_done;
+    int64_t moves;         /* AlphaZeroBot.step calls completed */
+    int64_t sims;          /* MCTS.playout calls completed */
+    int64_t evals;         /* policy_fn requests issued (leaf + root-Dirichlet) */
+    int64_t terminal_hits; /* playouts that ended on a terminal state (no evaluation) */
+    int64_t sum_depth;     /* Σ select depth over playouts */
+    int64_t sum_children;  /* Σ children scanned by select */
+    int64_t nodes_allocated;
+    int64_t compactions;
+    int64_t slots_waiting; /* slots with an evaluation request outstanding after the last advance */
+    int64_t slots_idle;
+    int64_t slots_search_done; /* manual_moves: slots whose S playouts are complete */
+    uint32_t error_flags; /* AZ_FAULT_* */
+    uint32_t reserved;
+} az_progress;
+
+/* Host view of finished games, valid until the next reset/export/destroy.
+ * Replaces the pickled list-of-games a pool returns (examplegenerator.py:151-152,172-173);
+ * the Python façade turns each ply into the reference's [key, board, pi, z] record
+ * (game_utils.py:169). */
+typedef struct az_example_view {
+    int64_t n_games;            /* finished games, ids 0..n_games-1 */
+    int32_t max_plies;          /* row stride of the per-ply arrays */
+    int32_t max_children;       /* row stride of counts/actions */
+    const int32_t *game_len;    /* [n_games] plies */
+    const float *game_ret0;     /* [n_games] returns()[0] */
+    const uint64_t *states;     /* [n_games][max_plies][2] bitboards (layout: az_games.h) */
+    const uint16_t *move;       /* [n_games][max_plies] action played */
+    const uint8_t *n_children;  /* [n_games][max_plies] number of root children (= legal actions) */
+    const uint16_t *child_action; /* [n_games][max_plies][max_children] ascending legal actions */
+    const uint32_t *child_visits; /* [n_games][max_plies][max_children] root child N before the move */
+    const double *value;        /* [n_games][max_plies] value target (soft-Z / A0C / off-policy; on-policy: filled from ret0) */
+} az_example_view;
+
+typedef struct az_engine az_engine;
+
+/* lifecycle ------------------------------------------------------------- */
+int az_engine_create(const az_config *cfg, az_engine **out);
+int az_engine_destroy(az_engine *e);
+const char *az_last_error(const az_engine *e); /* e may be NULL: error of the last failed create */
+int az_engine_sizes(const az_engine *e, az_sizes *out);
+
+/* Start a generation of n_games self-play games (ExampleGenerator.generate_examples(n_games),
+ * examplegenerator.py:164-175).  Game ids are 0..n_games-1; id i uses RNG stream (seed, i).
+ * Slots pick up ids in order and refill from a device-side counter as games finish. */
+int az_engine_reset(az_engine *e, uint64_t seed, int64_t n_games, void *stream);
+
+/* Parity mode (rng_mode = AZ_RNG_INJECTED): host arrays, copied.
+ * etas [n_games][max_plies][max_children]: the np.random.dirichlet draw of each move (mcts.py:187)
+ * us   [n_games][max_plies]: the uniform behind np.random.choice of each move (alphazerobot.py:84) */
+int az_engine_set_injected_rng(az_engine *e, const double *etas, const double *us, int64_t n_games);
+
+/* Start every slot from a given position instead of the initial one (test hook for mid-game search
+ * traces).  actions: host [n] action prefix applied to the initial state. Call after reset. */
+int az_engine_set_start_prefix(az_engine *e, const int32_t *actions, int32_t n);
+
+/*
+ * One tick = MCTS.playout's select + expand + backup (mcts.py:126-153) for all slots, fused with the
+ * agent's move step when a slot has finished its S playouts (alphazerobot.py:71-93,
+ * game_utils.py:156-197, mcts.py:155-162,192-203) and the root Dirichlet expansion (mcts.py:182-190):
+ *   1. consume priors[g]/values[g] for the request slot g issued on the PREVIOUS tick
+ *      (expand + backup, or root expansion); ignored for slots without a request;
+ *   2. run playouts/moves until the slot needs the network again, and write that state's
+ *      observation (state_to_board, network.py:9-18, float32) to obs_out[g].
+ * priors: dev float32 [G][A] (softmax output), values: dev float32 [G], obs_out: dev float32 [G][C+1][H][W].
+ * priors/values may be NULL on the first tick after reset.
+ */
+int az_engine_advance(az_engine *e, const float *priors, const float *values, float *obs_out, void *stream);
+
+/* MCTS.update_root(action) (mcts.py:192-203) for every slot, manual_moves engines only: applies
+ * actions[g] (host array [G]; -1 = leave the slot alone) to the slot's root state, keeps the chosen
+ * child's subtree (or starts a fresh tree when keep_subtree == 0 or the root is a leaf) and arms the
+ * next search.  A slot whose game ends goes idle. */
+int az_engine_update_root(az_engine *e, const int32_t *actions, int32_t keep_subtree, void *stream);
+
+/* Counters; synchronises `stream`. */
+int az_engine_progress(az_engine *e, az_progress *out, void *stream);
+
+/* Copy finished games to host memory owned by the engine; synchronises `stream`. */
+int az_engine_export(az_engine *e, az_example_view *out, void *stream);
+
+/* debug / parity read-back of one slot's root (mcts.root.{N,Q,children[a].{N,Q,P}}, read by
+ * game_utils.py:30-31,174,178,183-193).  Arrays sized max_children.  Returns n_children or <0.
+ * Synchronises the device. */
+int az_engine_read_root(az_engine *e, int32_t slot, int64_t *root_n, double *root_q, int32_t *actions,
+                        int64_t *child_n, double *child_q, double *child_p);
+
+/* The whole search tree of one slot in breadth-first order (node 0 = root; children of a node are
+ * consecutive and in ascending-action order): parent index, action leading to the node, N, Q, P.
+ * What deep-copying `mcts.root` gives the reference's statistics code (game_utils.py:30-31,183-193).
+ * Arrays sized max_nodes (any may be NULL).  Returns the node count, or <0; if the tree has more than max_nodes
+ * nodes the first max_nodes are written and the full count is returned.  Synchronises the device. */
+int64_t az_engine_read_tree(az_engine *e, int32_t slot, int64_t max_nodes, int32_t *parent, int32_t *action,
+                            int64_t *n, double *q, double *p);
+
+typedef struct az_slot_info {
+    int32_t phase; /* 0 idle, 1 run, 2 move pending, 3 waiting root eval, 4 waiting leaf eval, 5 search done (manual_moves) */
+    int32_t game_id, ply, sims_done;
+    uint32_t root, alloc;
+    uint64_t bb[2];      /* root state */
+    uint64_t leaf_bb[2]; /* state of the outstanding request */
+    int32_t leaf_ply, depth;
+} az_slot_info;
+int az_engine_read_slot(az_engine *e, int32_t slot, az_slot_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZ_ENGINE_H */

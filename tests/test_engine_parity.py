@@ -1,0 +1,236 @@
+"""GPU parity tests proper: the HIP engine, called through the C ABI (libaz_engine.so via ctypes),
+against (a) fixtures produced by running the real reference and (b) the C oracle on fresh seeded inputs.
+
+Bar: bit-exact.  Visit counts / actions / boards are integers; Q, P, pi and value targets are IEEE
+doubles compared with ==.  Both sides get identical float32 (priors, value) from oracle/fakepolicy.py
+and identical injected random draws, so no tolerance is needed or used.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import binding as orc
+from oracle import fakepolicy
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_mod():
+    from alphazero_openspiel_amd import engine
+    return engine
+
+
+def _board_fn(A, salt):
+    def fn(board):
+        pri, val = fakepolicy.fake_eval(board, A, salt)
+        return pri, val
+    return fn
+
+
+def _sparse_to_dense(d, A):
+    out = np.zeros(A)
+    for a, p in d.items():
+        out[int(a)] = p
+    return out
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_search_trace_matches_reference(idx):
+    """MCTS.playout by playout: root child N and root Q after every completed playout, full root
+    statistics (N, Q, P per child) at the end (mcts.py:126-190)."""
+    E = _engine_mod()
+    case = load_golden("mcts_trace.json")[idx]
+    S = case["n_playouts"]
+    eng = E.SelfPlayEngine(case["game"], 1, n_playouts=S, c_puct=case["c_puct"],
+                           use_dirichlet=case["use_dirichlet"], dirichlet_ratio=case["dirichlet_ratio"],
+                           manual_moves=True, rng="injected", max_games=1, max_sims_per_tick=1)
+    eng.set_start_prefix(case["prefix"])
+    eng.reset(1)
+    ply = len(case["prefix"])
+    eng.start_history = []
+    eng.set_injected_rng([[[0.0]] * ply + [case["eta"] or [0.0]]], [[0.0] * (ply + 1)])
+    obs, pri, val = eng.alloc_io()
+    ev = E.HostPolicyEvaluator(eng, _board_fn(eng.A, case["salt"]))
+    seen = set()
+    expanded_checked = not case["use_dirichlet"]
+    for _ in range(4 * S + 8):
+        eng.advance(pri, val, obs)
+        info = eng.read_slot(0)
+        k = info["sims_done"]
+        if info["phase"] == 5:
+            k = S
+        root = eng.read_root(0)
+        if not expanded_checked and root["actions"]:
+            assert k == 0
+            assert root == case["after_root_expand"]
+            expanded_checked = True
+        if k > 0 and k not in seen:
+            seen.add(k)
+            assert root["cN"] == case["trace_cN"][k - 1], "after playout %d" % k
+            assert root["Q"] == case["trace_rootQ"][k - 1], "after playout %d" % k
+        if info["phase"] == 5:
+            break
+        if info["phase"] in (3, 4):
+            ev(obs, pri, val)
+    else:
+        pytest.fail("search did not finish")
+    assert len(seen) >= S // 2 and S in seen
+    assert eng.read_root(0) == case["final"]
+    prog = eng.progress()
+    assert prog["sims"] == S and prog["error_flags"] == 0
+    eng.close()
+
+
+def _run_games(E, game, n_games, n_slots, salt, etas, us, **kw):
+    eng = E.SelfPlayEngine(game, n_slots, rng="injected", max_games=n_games, **kw)
+    eng.reset(n_games)
+    eng.set_injected_rng(etas, us)
+    ev = E.HostPolicyEvaluator(eng, _board_fn(eng.A, salt))
+    obs, pri, val = eng.alloc_io()
+    for _ in range(200000):
+        eng.advance(pri, val, obs)
+        ev(obs, pri, val)
+        if eng.progress()["games_done"] >= n_games:
+            break
+    else:
+        pytest.fail("games did not finish")
+    prog = eng.progress()
+    ex = eng.export()
+    games = E.examples_from_export(eng.game, ex)
+    eng.close()
+    return games, ex, prog
+
+
+@pytest.mark.parametrize("idx", range(13))
+def test_self_play_game_matches_reference(idx):
+    """play_game_self (game_utils.py:148-206) whole games: every move, every root visit vector, every
+    example record [key, board, pi, value] — all four value targets, temperature, no-Dirichlet and
+    fresh-tree variants, connect_four and breakthrough 6x6 / 8x8."""
+    E = _engine_mod()
+    g = load_golden("selfplay.json")[idx]
+    kw = {k: v for k, v in g["kwargs"].items() if k != "tree_strap"}
+    games, ex, prog = _run_games(E, g["game"], 1, 1, g["salt"], [g["etas"]] if g["etas"] else None, [g["us"]], **kw)
+    n = len(g["moves"])
+    assert int(ex["game_len"][0]) == n
+    assert ex["move"][0, :n].tolist() == [m["action"] for m in g["moves"]]
+    for i, m in enumerate(g["moves"]):
+        nc = int(ex["n_children"][0, i])
+        assert ex["child_action"][0, i, :nc].tolist() == m["root"]["actions"]
+        assert ex["child_visits"][0, i, :nc].tolist() == m["root"]["cN"]
+    A = len(games[0][0][2])
+    for got, want in zip(games[0], g["examples"]):
+        assert got[0] == want["key"]
+        assert "".join(str(int(x)) for x in got[1].reshape(-1)) == want["board"]
+        assert got[2] == _sparse_to_dense(want["pi"], A).tolist()
+        assert got[3] == want["value"]
+        assert isinstance(got, list) and isinstance(got[2], list) and isinstance(got[3], float)
+    assert prog["error_flags"] == 0 and prog["moves"] == n
+
+
+@pytest.mark.parametrize("game,S,n_games,n_slots,nodes", [
+    ("connect_four", 40, 9, 4, 0),
+    ("connect_four", 60, 6, 3, 1300),                     # tiny pools: forces Cheney compaction on re-root
+    ("breakthrough(rows=6,columns=6)", 24, 5, 2, 2600),
+    ("breakthrough(rows=5,columns=4)", 30, 6, 4, 0),
+])
+def test_batched_games_with_refill_match_oracle(game, S, n_games, n_slots, nodes):
+    """Several slots, more games than slots (device-side refill), optional pool compaction: every game must
+    equal the oracle's game with the same id's random draws, whichever slot played it."""
+    E = _engine_mod()
+    gid, rows, cols = orc.parse_game(game)
+    A = orc.lib().orc_num_actions(gid, rows, cols)
+    mp = orc.max_plies(gid, rows, cols)
+    rng = np.random.RandomState(1234 + S)
+    etas, us, want = [], [], []
+    salt = 77
+    for _ in range(n_games):
+        e = [rng.dirichlet(0.3 * np.ones(3 * rows * cols)).tolist() for _ in range(mp)]
+        u = rng.random_sample(mp).tolist()
+        # the oracle consumes eta[ply][:n_legal] — renormalisation is not required for parity
+        etas.append(e)
+        us.append(u)
+        want.append(orc.play_game_self(lambda b: fakepolicy.fake_eval(b, A, salt), game, n_playouts=S,
+                                       etas=e, us=u))
+    mc = min(64, 6 * cols) if gid else 7
+    games, ex, prog = _run_games(E, game, n_games, n_slots, salt, [[row[:mc] for row in e] for e in etas], us,
+                                 n_playouts=S, nodes_per_slot=nodes)
+    if nodes:
+        assert prog["compactions"] > 0
+    for i in range(n_games):
+        n = len(want[i]["actions"])
+        assert int(ex["game_len"][i]) == n
+        assert ex["move"][i, :n].tolist() == want[i]["actions"]
+        assert float(ex["game_ret0"][i]) == want[i]["ret0"]
+        for j in range(n):
+            nc = int(ex["n_children"][i, j])
+            assert ex["child_visits"][i, j, :nc].tolist() == want[i]["root_cN"][j]
+            assert games[i][j][2] == want[i]["examples"][j][2]
+            assert games[i][j][3] == want[i]["examples"][j][3]
+            assert (games[i][j][1] == want[i]["examples"][j][1]).all()
+    sims = sum(w["counters"]["sims"] for w in want)
+    evals = sum(w["counters"]["evals"] for w in want)
+    assert prog["sims"] == sims and prog["evals"] == evals
+    assert prog["sum_depth"] == sum(w["counters"]["sum_depth"] for w in want)
+    assert prog["terminal_hits"] == sum(w["counters"]["terminal_hits"] for w in want)
+    assert prog["sum_children"] == sum(w["counters"]["sum_children"] for w in want)
+
+
+def test_philox_mode_statistics():
+    """Production RNG (on-device Philox): Dirichlet(0.3) draws and visit-proportional move sampling are
+    checked statistically (north_star: 'within stochastic-sampling tolerance')."""
+    E = _engine_mod()
+    G = 512
+    eng = E.SelfPlayEngine("connect_four", G, n_playouts=8, max_games=G, seed=99)
+    eng.reset(G)
+    obs, pri, val = eng.alloc_io()   # uniform priors, zero values
+    eng.advance(pri, val, obs)       # root requests
+    eng.advance(pri, val, obs)       # consume root eval -> P = 0.75/7 + 0.25*eta
+    etas = []
+    for g in range(G):
+        r = eng.read_root(g)
+        eta = (np.array(r["cP"]) - 0.75 * float(np.float32(1.0 / 7))) / 0.25
+        etas.append(eta)
+    etas = np.array(etas)
+    assert np.allclose(etas.sum(1), 1.0, atol=1e-6) and (etas > -1e-9).all()
+    # Dirichlet(a,...,a) with a=0.3, n=7: mean 1/7, var = (1/7)(6/7)/(7a+1)
+    assert abs(etas.mean() - 1 / 7) < 1e-9 * 7 + 1e-6
+    var = etas.var(0).mean()
+    assert abs(var - (1 / 7) * (6 / 7) / (7 * 0.3 + 1)) < 0.01
+    # distinct games draw distinct noise
+    assert len({tuple(np.round(e, 12)) for e in etas}) == G
+    # finish the first move everywhere and compare the sampled first moves with the visit distribution
+    for _ in range(64):
+        eng.advance(pri, val, obs)
+        if eng.progress()["moves"] >= G:
+            break
+    for g in range(G):
+        assert eng.read_slot(g)["ply"] >= 1
+    eng.close()
+
+
+def test_error_paths():
+    E = _engine_mod()
+    with pytest.raises(E.EngineError):
+        E.SelfPlayEngine("connect_four", 0)
+    with pytest.raises(E.EngineError):
+        E.SelfPlayEngine("breakthrough(rows=3,columns=20)", 4)
+    with pytest.raises(E.EngineError):
+        E.SelfPlayEngine("connect_four", 2, device="cpu")
+    eng = E.SelfPlayEngine("connect_four", 2, n_playouts=4)
+    obs, pri, val = eng.alloc_io()
+    with pytest.raises(E.EngineError):  # advance before reset
+        eng.advance(pri, val, obs)
+    eng.reset(2)
+    with pytest.raises(E.EngineError):  # wrong shape
+        eng.advance(pri[:1], val, obs)
+    eng.advance(pri, val, obs)
+    bad = torch.full_like(pri, float("nan"))
+    eng.advance(bad, val, obs)
+    with pytest.raises(E.EngineError) as ei:
+        eng.progress()
+    assert "BAD_PRIOR" in str(ei.value)
+    eng.close()
+    # pool too small for even one search
+    with pytest.raises(E.EngineError):
+        E.SelfPlayEngine("connect_four", 2, n_playouts=100, nodes_per_slot=50)
