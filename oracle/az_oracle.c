@@ -620,6 +620,8 @@ typedef struct {
     int32_t n_playouts, use_dirichlet, use_puct, keep_search_tree, backup;
     double c_puct, dirichlet_ratio, temperature;
     uint64_t seed; /* used only when etas/us are NULL */
+    int32_t max_moves; /* >0: stop after this many moves (bounded timing sample); 0 = play to the end */
+    int32_t reserved;
 } orc_selfplay_cfg;
 
 /* off-policy / A0GB target (game_utils.py:182-194) */
@@ -670,7 +672,7 @@ int orc_play_game_self(const orc_selfplay_cfg *cfg, orc_policy_fn fn, void *user
     double eta_buf[ORC_MAX_CELLS * 3];
     int32_t legal[ORC_MAX_CELLS * 3];
     int ply = 0;
-    while (!orc_is_terminal(&st)) {
+    while (!orc_is_terminal(&st) && !(cfg->max_moves > 0 && ply >= cfg->max_moves)) {
         if (ply >= max_plies) {
             orc_bot_free(bot);
             return -1;

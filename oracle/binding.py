@@ -24,7 +24,7 @@ class SelfplayCfg(C.Structure):
                 ("n_playouts", C.c_int32), ("use_dirichlet", C.c_int32), ("use_puct", C.c_int32),
                 ("keep_search_tree", C.c_int32), ("backup", C.c_int32),
                 ("c_puct", C.c_double), ("dirichlet_ratio", C.c_double), ("temperature", C.c_double),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("max_moves", C.c_int32), ("reserved", C.c_int32)]
 
 
 def build(force=False):
@@ -237,7 +237,7 @@ def max_plies(game, rows, cols):
 
 def play_game_self(py_policy, game_name, n_playouts=100, c_puct=2.5, temperature=1.0, dirichlet_ratio=0.25,
                    use_dirichlet=True, use_puct=True, keep_search_tree=True, backup="on-policy",
-                   etas=None, us=None, seed=0, **_ignored):
+                   etas=None, us=None, seed=0, max_moves=0, **_ignored):
     """game_utils.py:148-206 through the C restatement.
 
     Returns dict(examples=[[key, board(4,H,W) f64, pi list[A], value]], actions, root_cN, ret0, counters)."""
@@ -246,7 +246,7 @@ def play_game_self(py_policy, game_name, n_playouts=100, c_puct=2.5, temperature
     A = L.orc_num_actions(g, r, c)
     mp = max_plies(g, r, c)
     cfg = SelfplayCfg(g, r, c, n_playouts, int(use_dirichlet), int(use_puct), int(keep_search_tree),
-                      BACKUPS[backup], c_puct, dirichlet_ratio, temperature, seed)
+                      BACKUPS[backup], c_puct, dirichlet_ratio, temperature, seed, int(max_moves), 0)
     cb = wrap_policy(py_policy, A, 4 * r * c)
     stride = 3 * r * c
     eta_arr = None
