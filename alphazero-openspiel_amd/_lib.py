@@ -51,7 +51,14 @@ class AzSlotInfo(C.Structure):
                 ("leaf_ply", C.c_int32), ("depth", C.c_int32)]
 
 
-# every symbol include/az_engine.h declares: (name, restype, argtypes)
+class AzNetDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("in_planes", C.c_int32),
+                ("n_filters", C.c_int32), ("n_blocks", C.c_int32), ("num_actions", C.c_int32), ("device", C.c_int32),
+                ("conv_w", C.POINTER(C.c_uint16)), ("conv_epi", C.POINTER(C.c_float)),
+                ("in_affine", C.POINTER(C.c_float)), ("fc_w", C.POINTER(C.c_uint16)), ("fc_b", C.POINTER(C.c_float))]
+
+
+# every symbol include/az_engine.h and include/az_net.h declare: (name, restype, argtypes)
 _vp = C.c_void_p
 PROTOTYPES = [
     ("az_engine_create", C.c_int, [C.POINTER(AzConfig), C.POINTER(_vp)]),
@@ -71,6 +78,12 @@ PROTOTYPES = [
     ("az_engine_read_slot", C.c_int, [_vp, C.c_int32, C.POINTER(AzSlotInfo)]),
     ("az_engine_read_tree", C.c_int64, [_vp, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("az_net_create", C.c_int, [C.POINTER(AzNetDesc), C.POINTER(_vp)]),
+    ("az_net_destroy", C.c_int, [_vp]),
+    ("az_net_last_error", C.c_char_p, [_vp]),
+    ("az_net_forward", C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),
+    ("az_net_reserve", C.c_int, [_vp, C.c_int32]),
+    ("az_net_read_tower", C.c_int, [_vp, C.POINTER(C.c_float), C.c_int32]),
 ]
 
 _lib = None

@@ -1,0 +1,466 @@
+// az_net.hip — fused PV-net inference for gfx950 (MI355X): the whole residual tower in ONE kernel.
+//
+// Reference computation: Net.forward / ResidualBlock.forward (network.py:48-64,99-104) in eval mode.
+// Mapping (weights pre-packed by alphazero-openspiel_amd/fusednet.py, see include/az_net.h):
+//   * a wavefront owns BPW whole boards; their activations never leave the CU: one fp16 LDS image
+//     [board][cell][56 ch] with a zero halo (cell = (y+1)*(W+1) + (x+1); the halo column is shared between
+//     rows), rewritten in place layer after layer; the fp32 residual stream lives in registers.
+//   * every 3x3 conv is an implicit GEMM on v_mfma_f32_16x16x32_f16:  D[co][n] += Wp[co][k] * Act[k][n],
+//     n = (board, position) over the wave's boards, k = 64 groups x 8 channels (group -> tap, channel
+//     octet; group 63 = raw input planes, carries block 1's 1x1 skip).  M = 64 output channels (4 tiles),
+//     so the accumulator of lane l holds 4 CONSECUTIVE channels of one position: the epilogue
+//     (bias, LeakyReLU, next BN scale/shift) packs them to fp16 and writes 8 bytes back to the image.
+//   * weights are the A operand, shared by all waves of the workgroup: streamed L2 -> LDS by
+//     global_load_lds (16 B/lane) in 16 KiB chunks (4 k-steps), double buffered, one barrier per chunk.
+//     They are stored fragment-linear, so an A fragment is one contiguous KiB (conflict-free ds_read_b128).
+// The fc1 + softmax + tanh head is a second small MFMA kernel over the tower output (fp16, [B][HW][64]).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/az_engine.h"
+#include "../../include/az_net.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CELL_B (AZ_NET_CPAD * 2) // 112 bytes per cell
+#define X0_B 16                  // raw input planes: 8 fp16 per cell
+#define CHUNK_KS 4               // k-steps per weight chunk
+#define CHUNK_B (CHUNK_KS * 4 * 64 * 16)
+#define WAVES 4
+
+struct TowerParams {
+    int H, W, HW, cells, cin, n_convs, n_boards, bpw, zero_b;
+    int off_zero, off_x0, off_act; // LDS byte offsets (weights buffers at 0 and CHUNK_B)
+    const _Float16 *conv_w;
+    const float *epi;
+    float in_scale[8], in_shift[8];
+    const float *obs;
+    _Float16 *xout;
+};
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.01f * v; }
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void az_tower_kernel(TowerParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l15 = lane & 15;
+    const int W1 = p.W + 1;
+    const int board0 = (blockIdx.x * WAVES + wave) * p.bpw; // first global board of this wave
+
+    // ---- zero the wave's private images and (wave 0) the shared zero region ---------------------------
+    {
+        const int act_b = p.bpw * p.cells * CELL_B, x0_b = p.bpw * p.cells * X0_B;
+        uint4 z = {0, 0, 0, 0};
+        unsigned char *act = lds + p.off_act + wave * act_b, *x0 = lds + p.off_x0 + wave * x0_b;
+        for (int i = lane * 16; i < act_b; i += 64 * 16) *(uint4 *)(act + i) = z;
+        for (int i = lane * 16; i < x0_b; i += 64 * 16) *(uint4 *)(x0 + i) = z;
+        if (wave == 0)
+            for (int i = lane * 16; i < p.zero_b; i += 64 * 16) *(uint4 *)(lds + p.off_zero + i) = z;
+    }
+    // ---- per-lane address tables ------------------------------------------------------------------------
+    int pos_addr[NT], x0_addr[NT], grow[NT]; // LDS byte offsets of column n's cell; global row of xout (or -1)
+    const int zero_mid = p.off_zero + ((p.zero_b / 2) & ~15);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        int n = nt * 16 + l15;
+        int b = n / p.HW, pos = n - b * p.HW;
+        bool ok = (b < p.bpw) && (board0 + b < p.n_boards);
+        int y = pos / p.W, x = pos - y * p.W;
+        int cell = (y + 1) * W1 + (x + 1);
+        pos_addr[nt] = ok ? p.off_act + ((wave * p.bpw + b) * p.cells + cell) * CELL_B : zero_mid;
+        x0_addr[nt] = ok ? p.off_x0 + ((wave * p.bpw + b) * p.cells + cell) * X0_B : zero_mid;
+        grow[nt] = ok ? (board0 + b) * p.HW + pos : -1;
+    }
+    int koff[AZ_NET_KSTEPS]; // byte offset of (tap, channel octet) for this lane's k-group in each k-step
+#pragma unroll
+    for (int ks = 0; ks < AZ_NET_KSTEPS; ks++) {
+        int g = 4 * ks + q;
+        int tap = g / 7, c8 = g - tap * 7;
+        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        koff[ks] = (dy * W1 + dx) * CELL_B + c8 * 16;
+    }
+    // ---- input prologue: raw planes -> x0 image; a = lrelu(bn1(x0)) -> channels 0..cin-1 of the act image --
+    for (int b = 0; b < p.bpw; b++) {
+        int gb = board0 + b;
+        if (gb >= p.n_boards) break;
+        for (int pos = lane; pos < p.HW; pos += 64) {
+            int y = pos / p.W, x = pos - y * p.W;
+            int cell = (y + 1) * W1 + (x + 1);
+            half8 raw = {0, 0, 0, 0, 0, 0, 0, 0};
+            half4 a4 = {0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (c < p.cin) {
+                    float v = p.obs[((size_t)gb * p.cin + c) * p.HW + pos];
+                    raw[c] = (_Float16)v;
+                    a4[c] = (_Float16)lrelu(p.in_scale[c] * v + p.in_shift[c]);
+                }
+            *(half8 *)(lds + p.off_x0 + ((wave * p.bpw + b) * p.cells + cell) * X0_B) = raw;
+            *(half4 *)(lds + p.off_act + ((wave * p.bpw + b) * p.cells + cell) * CELL_B) = a4;
+        }
+    }
+
+    f32x4 acc[4][NT], xres[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            xres[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+
+    // ---- weight stream: chunk c of 16 KiB -> buffer c&1, by LDS-DMA -----------------------------------
+    const int n_chunks = p.n_convs * (AZ_NET_KSTEPS / CHUNK_KS);
+    auto issue_chunk = [&](int c) {
+        const unsigned char *src = (const unsigned char *)p.conv_w + (size_t)c * CHUNK_B;
+        unsigned char *dst = lds + (c & 1) * CHUNK_B;
+#pragma unroll
+        for (int i = 0; i < CHUNK_B / (256 * 16); i++) {
+            int piece = i * WAVES + wave; // one KiB per wave-instruction, lane-linear
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    issue_chunk(0);
+
+    int chunk = 0;
+    for (int conv = 0; conv < p.n_convs; conv++) {
+#pragma unroll
+        for (int part = 0; part < AZ_NET_KSTEPS / CHUNK_KS; part++, chunk++) {
+            __syncthreads(); // chunk's DMA landed for every wave (vmcnt(0) precedes the barrier); other buffer is free
+            if (chunk + 1 < n_chunks) issue_chunk(chunk + 1);
+            const unsigned char *wb = lds + (chunk & 1) * CHUNK_B;
+#pragma unroll
+            for (int ksl = 0; ksl < CHUNK_KS; ksl++) {
+                const int ks = part * CHUNK_KS + ksl;
+                half8 a[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) a[mt] = *(const half8 *)(wb + ((ksl * 4 + mt) * 64 + lane) * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    int addr = pos_addr[nt] + koff[ks];
+                    if (ks == AZ_NET_KSTEPS - 1 && q == 3) addr = x0_addr[nt]; // group 63: raw input planes
+                    half8 b = *(const half8 *)(lds + addr);
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b, acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue of this conv (the wave's own boards only: no barrier needed) ------------------------
+        const float *ep = p.epi + (size_t)conv * 3 * 64;
+        const bool is_conv2 = conv & 1, last = conv == p.n_convs - 1;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const int co0 = 16 * mt + 4 * q;
+            f32x4 bias = *(const f32x4 *)(ep + co0);
+            f32x4 sc = *(const f32x4 *)(ep + 64 + co0), sh = *(const f32x4 *)(ep + 128 + co0);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                f32x4 v = acc[mt][nt] + bias;
+                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                half4 o;
+                if (!is_conv2) { // u = lrelu(conv1'(a) + b1')
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (_Float16)lrelu(v[r]);
+                } else { // x += conv2(u) + b2 ; a = lrelu(bn1_next(x))
+                    f32x4 xv = xres[mt][nt] + v;
+                    xres[mt][nt] = xv;
+                    if (last) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) o[r] = (_Float16)xv[r];
+                        if (grow[nt] >= 0) *(half4 *)(p.xout + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = o;
+                        continue;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (_Float16)lrelu(sc[r] * xv[r] + sh[r]);
+                }
+                if (grow[nt] >= 0 && co0 < AZ_NET_CPAD) *(half4 *)(lds + pos_addr[nt] + co0 * 2) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fc1 + softmax + tanh (network.py:61-64).  One workgroup = 16 boards; the K = HW*64 reduction is split
+// over the 4 waves (k-step ks goes to wave ks & 3), partial tiles are summed through LDS.
+struct HeadParams {
+    int HW, A, n_ot, ksteps, n_boards;
+    const _Float16 *x;    // [B][HW*64]
+    const _Float16 *fc_w; // [n_ot][ksteps][64][8]
+    const float *fc_b;
+    float *priors, *values;
+};
+
+#define OTG 8
+__global__ __launch_bounds__(256) void az_head_kernel(HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float *part = (float *)lds;                         // [4 waves][OTG][64 lanes][4]
+    float *logits = (float *)(lds + 4 * OTG * 64 * 16); // [16][n_ot*16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l15 = lane & 15;
+    const int b0 = blockIdx.x * 16;
+    const int K = p.HW * AZ_NET_XOUT_C, NP = p.n_ot * 16;
+    int row = b0 + l15;
+    if (row >= p.n_boards) row = p.n_boards - 1; // clamp: computed, never stored
+    const _Float16 *xrow = p.x + (size_t)row * K + 8 * q;
+    for (int og = 0; og < p.n_ot; og += OTG) {
+        f32x4 acc[OTG];
+#pragma unroll
+        for (int o = 0; o < OTG; o++) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = wave; ks < p.ksteps; ks += 4) {
+            half8 a = *(const half8 *)(xrow + 32 * ks);
+#pragma unroll
+            for (int o = 0; o < OTG; o++)
+                if (og + o < p.n_ot) {
+                    half8 w = *(const half8 *)(p.fc_w + (((size_t)(og + o) * p.ksteps + ks) * 64 + lane) * 8);
+                    acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w, acc[o], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int o = 0; o < OTG; o++) *(f32x4 *)(part + ((wave * OTG + o) * 64 + lane) * 4) = acc[o];
+        __syncthreads();
+        // 256 threads sum the 4 partials of OTG*64 float4 slots (= 512 slots: two per thread)
+        for (int s = tid; s < OTG * 64; s += 256) {
+            int o = s >> 6, ln = s & 63;
+            if (og + o >= p.n_ot) continue;
+            f32x4 v = *(f32x4 *)(part + ((0 * OTG + o) * 64 + ln) * 4);
+#pragma unroll
+            for (int w = 1; w < 4; w++) v += *(f32x4 *)(part + ((w * OTG + o) * 64 + ln) * 4);
+            int col = 16 * (og + o) + (ln & 15);
+            float bias = p.fc_b[col];
+#pragma unroll
+            for (int r = 0; r < 4; r++) logits[((ln >> 4) * 4 + r) * NP + col] = v[r] + bias; // D: row = 4q+r, col = l15
+        }
+        __syncthreads();
+    }
+    // softmax over the first A logits, tanh of logit A: 16 lanes per board
+    const int brd = tid >> 4, sub = tid & 15;
+    const float *lg = logits + brd * NP;
+    float mx = -INFINITY;
+    for (int o = sub; o < p.A; o += 16) mx = fmaxf(mx, lg[o]);
+#pragma unroll
+    for (int off = 8; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
+    float sum = 0.f;
+    for (int o = sub; o < p.A; o += 16) sum += __expf(lg[o] - mx);
+#pragma unroll
+    for (int off = 8; off; off >>= 1) sum += __shfl_xor(sum, off, 16);
+    if (b0 + brd < p.n_boards) {
+        float inv = 1.f / sum;
+        float *out = p.priors + (size_t)(b0 + brd) * p.A;
+        for (int o = sub; o < p.A; o += 16) out[o] = __expf(lg[o] - mx) * inv;
+        if (sub == 0) p.values[b0 + brd] = tanhf(lg[p.A]);
+    }
+}
+
+// ================================================================================================
+struct az_net {
+    az_net_desc d;
+    std::string err;
+    _Float16 *conv_w = nullptr, *fc_w = nullptr, *xout = nullptr;
+    float *epi = nullptr, *fc_b = nullptr;
+    float in_affine[16];
+    int max_boards = 0;
+    int bpw = 0, nt = 0, cells = 0, zero_b = 0, lds_tower = 0, lds_head = 0, n_ot = 0;
+};
+static std::string g_net_err;
+
+#define NCHK(n, call)                                                        \
+    do {                                                                     \
+        hipError_t _s = (call);                                              \
+        if (_s != hipSuccess) {                                              \
+            (n)->err = std::string(#call) + ": " + hipGetErrorString(_s);    \
+            return AZ_E_HIP;                                                 \
+        }                                                                    \
+    } while (0)
+
+extern "C" const char *az_net_last_error(const az_net *n) { return n ? n->err.c_str() : g_net_err.c_str(); }
+
+extern "C" int az_net_destroy(az_net *n) {
+    if (!n) return AZ_OK;
+    (void)hipSetDevice(n->d.device);
+    (void)hipFree(n->conv_w);
+    (void)hipFree(n->fc_w);
+    (void)hipFree(n->xout);
+    (void)hipFree(n->epi);
+    (void)hipFree(n->fc_b);
+    delete n;
+    return AZ_OK;
+}
+
+static int tower_lds_bytes(int bpw, int cells, int zero_b) { return 2 * CHUNK_B + zero_b + WAVES * bpw * cells * (CELL_B + X0_B); }
+
+extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
+    if (!desc || !out) {
+        g_net_err = "null argument";
+        return AZ_E_INVALID;
+    }
+    *out = nullptr;
+    if (desc->struct_size != (int32_t)sizeof(az_net_desc)) {
+        g_net_err = "az_net_desc.struct_size mismatch";
+        return AZ_E_INVALID;
+    }
+    const az_net_desc &d = *desc;
+    if (d.rows < 3 || d.cols < 3 || d.rows * d.cols > 64 || d.in_planes < 1 || d.in_planes > 4 || d.n_filters < 1 ||
+        d.n_filters > AZ_NET_CPAD || d.n_blocks < 1 || d.num_actions < 1 || !d.conv_w || !d.conv_epi || !d.in_affine ||
+        !d.fc_w || !d.fc_b) {
+        g_net_err = "bad net description (need 3<=rows,cols, rows*cols<=64, in_planes<=4, n_filters<=56, packed buffers)";
+        return AZ_E_INVALID;
+    }
+    az_net *n = new az_net();
+    n->d = d;
+    memcpy(n->in_affine, d.in_affine, sizeof n->in_affine);
+    const int HW = d.rows * d.cols;
+    n->cells = (d.rows + 2) * (d.cols + 1) + 1;
+    n->zero_b = (2 * (d.cols + 2) * CELL_B + 256 + 15) & ~15;
+    // boards per wave: fill up to 9 column tiles (144 columns) within the 160 KiB LDS
+    int best = 0;
+    for (int bpw = 1; bpw <= 8; bpw++) {
+        int nt = (bpw * HW + 15) / 16;
+        if (nt > 9 || tower_lds_bytes(bpw, n->cells, n->zero_b) > 160 * 1024) break;
+        best = bpw;
+    }
+    if (!best) {
+        g_net_err = "board does not fit the tower kernel's LDS budget";
+        delete n;
+        return AZ_E_INVALID;
+    }
+    n->bpw = best;
+    n->nt = (best * HW + 15) / 16;
+    if (n->nt < 6) n->nt = 6;
+    n->lds_tower = tower_lds_bytes(best, n->cells, n->zero_b);
+    n->n_ot = (d.num_actions + 1 + 15) / 16;
+    n->lds_head = 4 * OTG * 64 * 16 + 16 * n->n_ot * 16 * 4;
+    hipError_t s = hipSetDevice(d.device);
+    if (s != hipSuccess) {
+        g_net_err = std::string("hipSetDevice: ") + hipGetErrorString(s);
+        delete n;
+        return AZ_E_HIP;
+    }
+    size_t cw = (size_t)2 * d.n_blocks * AZ_NET_KSTEPS * 4 * 64 * 8 * 2, ep = (size_t)2 * d.n_blocks * 3 * 64 * 4;
+    size_t fw = (size_t)n->n_ot * (HW * AZ_NET_XOUT_C / 32) * 64 * 8 * 2, fb = (size_t)n->n_ot * 16 * 4;
+    int rc = AZ_OK;
+    auto up = [&](void **dst, const void *src, size_t bytes) {
+        if (rc != AZ_OK) return;
+        if (hipMalloc(dst, bytes) != hipSuccess || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            g_net_err = "hipMalloc/hipMemcpy of the packed weights failed";
+            rc = AZ_E_NOMEM;
+        }
+    };
+    up((void **)&n->conv_w, d.conv_w, cw);
+    up((void **)&n->epi, d.conv_epi, ep);
+    up((void **)&n->fc_w, d.fc_w, fw);
+    up((void **)&n->fc_b, d.fc_b, fb);
+    if (rc != AZ_OK) {
+        az_net_destroy(n);
+        return rc;
+    }
+    n->d.conv_w = nullptr; // host pointers are not kept
+    n->d.conv_epi = nullptr;
+    n->d.in_affine = nullptr;
+    n->d.fc_w = nullptr;
+    n->d.fc_b = nullptr;
+    *out = n;
+    return AZ_OK;
+}
+
+extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
+    if (!n || max_boards < 1) return AZ_E_INVALID;
+    NCHK(n, hipSetDevice(n->d.device));
+    if (n->xout) (void)hipFree(n->xout);
+    n->xout = nullptr;
+    size_t bytes = (size_t)max_boards * n->d.rows * n->d.cols * AZ_NET_XOUT_C * 2;
+    NCHK(n, hipMalloc((void **)&n->xout, bytes));
+    NCHK(n, hipMemset(n->xout, 0, bytes));
+    n->max_boards = max_boards;
+    return AZ_OK;
+}
+
+template <int NT> static hipError_t launch_tower(const az_net *n, const TowerParams &tp, int grid, hipStream_t st) {
+    static bool attr_set[16] = {false};
+    if (!attr_set[n->d.device & 15]) {
+        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (s != hipSuccess) return s;
+        attr_set[n->d.device & 15] = true;
+    }
+    hipLaunchKernelGGL((az_tower_kernel<NT>), dim3(grid), dim3(256), n->lds_tower, st, tp);
+    return hipGetLastError();
+}
+
+extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float *values, int32_t n_boards, void *stream) {
+    if (!n || !obs || !priors || !values || n_boards < 1) return AZ_E_INVALID;
+    if (n_boards > n->max_boards) {
+        n->err = "n_boards exceeds az_net_reserve()";
+        return AZ_E_STATE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    TowerParams tp;
+    tp.H = n->d.rows;
+    tp.W = n->d.cols;
+    tp.HW = tp.H * tp.W;
+    tp.cells = n->cells;
+    tp.cin = n->d.in_planes;
+    tp.n_convs = 2 * n->d.n_blocks;
+    tp.n_boards = n_boards;
+    tp.bpw = n->bpw;
+    tp.zero_b = n->zero_b;
+    tp.off_zero = 2 * CHUNK_B;
+    tp.off_x0 = tp.off_zero + n->zero_b;
+    tp.off_act = tp.off_x0 + WAVES * n->bpw * n->cells * X0_B;
+    tp.conv_w = n->conv_w;
+    tp.epi = n->epi;
+    memcpy(tp.in_scale, n->in_affine, 32);
+    memcpy(tp.in_shift, n->in_affine + 8, 32);
+    tp.obs = obs;
+    tp.xout = n->xout;
+    int per_wg = WAVES * n->bpw, grid = (n_boards + per_wg - 1) / per_wg;
+    hipError_t s;
+    switch (n->nt) {
+    case 6: s = launch_tower<6>(n, tp, grid, st); break;
+    case 7: s = launch_tower<7>(n, tp, grid, st); break;
+    case 8: s = launch_tower<8>(n, tp, grid, st); break;
+    default: s = launch_tower<9>(n, tp, grid, st); break;
+    }
+    if (s != hipSuccess) {
+        n->err = std::string("tower launch: ") + hipGetErrorString(s);
+        return AZ_E_HIP;
+    }
+    HeadParams hp;
+    hp.HW = tp.HW;
+    hp.A = n->d.num_actions;
+    hp.n_ot = n->n_ot;
+    hp.ksteps = tp.HW * AZ_NET_XOUT_C / 32;
+    hp.n_boards = n_boards;
+    hp.x = n->xout;
+    hp.fc_w = n->fc_w;
+    hp.fc_b = n->fc_b;
+    hp.priors = priors;
+    hp.values = values;
+    {
+        static bool head_attr[16] = {false};
+        if (!head_attr[n->d.device & 15]) {
+            NCHK(n, hipFuncSetAttribute((const void *)az_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            head_attr[n->d.device & 15] = true;
+        }
+    }
+    hipLaunchKernelGGL(az_head_kernel, dim3((n_boards + 15) / 16), dim3(256), n->lds_head, st, hp);
+    NCHK(n, hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_net_read_tower(az_net *n, float *out, int32_t n_boards) {
+    if (!n || !out || n_boards < 1 || n_boards > n->max_boards) return AZ_E_INVALID;
+    NCHK(n, hipSetDevice(n->d.device));
+    NCHK(n, hipDeviceSynchronize());
+    size_t cnt = (size_t)n_boards * n->d.rows * n->d.cols * AZ_NET_XOUT_C;
+    std::vector<_Float16> h(cnt);
+    NCHK(n, hipMemcpy(h.data(), n->xout, cnt * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < cnt; i++) out[i] = (float)h[i];
+    return AZ_OK;
+}

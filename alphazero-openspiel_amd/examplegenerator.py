@@ -38,7 +38,8 @@ class ExampleGenerator:
         # engine extensions (not reference keywords)
         self.n_slots = kwargs.get("n_slots")           # concurrent games per GPU; default min(n_games, 4096)
         self.seed = int(kwargs.get("seed", np.random.randint(0, 2 ** 31 - 1)))
-        self.eval_dtype = kwargs.get("eval_dtype", torch.float32)
+        self.eval_backend = kwargs.get("eval_backend", "fused")   # "fused" (csrc/az_net.hip) | "torch"
+        self.eval_dtype = kwargs.get("eval_dtype", torch.float32)   # torch backend only
         self.use_graph = bool(kwargs.get("use_graph", True))
         self.last_progress = None
         self._generation = 0
@@ -59,7 +60,11 @@ class ExampleGenerator:
         engine = SelfPlayEngine(self.game, n_slots, max_games=n_local, device=self.device,
                                 seed=self.seed + 1000003 * self._generation + 7919 * rank, **self._engine_kwargs())
         try:
-            evaluator = DeviceEvaluator(self.net, self.device, dtype=self.eval_dtype)
+            if self.eval_backend == "fused":
+                from .fusednet import FusedNet
+                evaluator = FusedNet(self.net, self.device, max_boards=n_slots)
+            else:
+                evaluator = DeviceEvaluator(self.net, self.device, dtype=self.eval_dtype)
             self.last_progress = run_selfplay(engine, evaluator, n_local, use_graph=self.use_graph)
             packed = azdist.pack_export(engine.export())
         finally:

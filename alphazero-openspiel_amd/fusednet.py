@@ -1,0 +1,257 @@
+"""Fused PV-net inference (csrc/az_net.hip, C ABI include/az_net.h): host-side weight packing + handle.
+
+What the kernel computes is exactly `Net.forward` in eval mode (reference network.py:48-64,99-104):
+
+    x0 = board planes                                   a  = lrelu(bn1_1(x0))
+    block b:  u = lrelu(bn2_b(conv1_b(a)))              -> bn2 folded into conv1:  u = lrelu(conv1'_b(a) + b1'_b)
+              x = skip + conv2_b(u) + b2_b              (skip = x, or conv3_1(x0)+b3_1 for block 1)
+              a = lrelu(bn1_{b+1}(x))                   -> per-channel scale/shift prologue of the next block
+    logits = fc1(flatten_NCHW(x));  priors = softmax(logits[:A]);  value = tanh(logits[A])
+
+3x3 convs are implicit GEMMs on the MFMA units: D[co][n] = sum_k Wp[co][k] * Act[k][n], n = (board, position),
+k = 64 "groups" x 8 channels: group g < 63 -> (tap, c8) = divmod(g, 7), channel = 8*c8 + j, tap -> (dy,dx) =
+(tap//3-1, tap%3-1); group 63 reads the raw input planes and carries block 1's 1x1 skip conv (conv3) —
+zero for every other conv.  So every conv is exactly 16 k-steps of 32.
+
+Weights are stored in "fragment-linear" order: for k-step ks, output tile mt, lane l, element j:
+    co = 16*mt + (l & 15),  group = 4*ks + (l >> 4)
+which is the v_mfma_f32_16x16x32_f16 A-operand map, so a wave reads one contiguous KiB per fragment.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+CPAD = 56
+KSTEPS = 16
+NGROUPS = 64
+XOUT_C = 64
+LRELU = 0.01
+
+
+def _bn_affine(bn):
+    s = (bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps))
+    t = bn.bias.detach().double() - bn.running_mean.detach().double() * s
+    return s.numpy(), t.numpy()
+
+
+def _pack_conv(w3x3, skip_w=None):
+    """w3x3: float64 [F, Cin, 3, 3] (already folded) -> fp16 bits [16, 4, 64, 8]; skip_w: [F, Cs] 1x1 weights."""
+    F_, cin = w3x3.shape[0], w3x3.shape[1]
+    assert F_ <= 64 and cin <= CPAD
+    dense = np.zeros((64, NGROUPS, 8), dtype=np.float64)  # [co][group][j]
+    for g in range(63):
+        tap, c8 = divmod(g, 7)
+        ky, kx = divmod(tap, 3)
+        for j in range(8):
+            ci = 8 * c8 + j
+            if ci < cin:
+                dense[:F_, g, j] = w3x3[:, ci, ky, kx]
+    if skip_w is not None:
+        dense[:F_, 63, :skip_w.shape[1]] = skip_w
+    out = np.zeros((KSTEPS, 4, 64, 8), dtype=np.float16)
+    lane = np.arange(64)
+    for ks in range(KSTEPS):
+        for mt in range(4):
+            out[ks, mt] = dense[16 * mt + (lane & 15), 4 * ks + (lane >> 4), :].astype(np.float16)
+    return out.view(np.uint16)
+
+
+def pack_net(net):
+    """Net (alphazero_openspiel_amd.network.Net or the reference's Net) -> dict of packed numpy arrays."""
+    net = net.eval()
+    F_ = net.n_filts
+    blocks = [getattr(net, "resblock%d" % (i + 1)) for i in range(getattr(net, "n_blocks", 5))]
+    H, W, A = net.height, net.width, net.num_distinct_actions
+    cin0 = net.num_filters_input
+    if F_ > CPAD or cin0 > 8:
+        raise ValueError("fused net supports n_filters <= %d and <= 8 input planes" % CPAD)
+    nb = len(blocks)
+    conv_w = np.zeros((2 * nb, KSTEPS, 4, 64, 8), dtype=np.uint16)
+    epi = np.zeros((2 * nb, 3, 64), dtype=np.float32)
+    epi[:, 1, :] = 1.0
+    s_in, t_in = _bn_affine(blocks[0].bn1)
+    in_affine = np.zeros((2, 8), dtype=np.float32)
+    in_affine[0, :cin0], in_affine[1, :cin0] = s_in, t_in
+    for b, blk in enumerate(blocks):
+        s2, t2 = _bn_affine(blk.bn2)
+        w1 = blk.conv1.weight.detach().double().numpy() * s2[:, None, None, None]
+        b1 = blk.conv1.bias.detach().double().numpy() * s2 + t2
+        conv_w[2 * b] = _pack_conv(w1)
+        epi[2 * b, 0, :F_] = b1
+        w2 = blk.conv2.weight.detach().double().numpy()
+        b2 = blk.conv2.bias.detach().double().numpy().copy()
+        skip = None
+        if blk.use_1x1conv:
+            if b != 0:
+                raise ValueError("a 1x1 skip conv is only supported on the first block")
+            skip = blk.conv3.weight.detach().double().numpy()[:, :, 0, 0]
+            b2 = b2 + blk.conv3.bias.detach().double().numpy()
+        conv_w[2 * b + 1] = _pack_conv(w2, skip)
+        epi[2 * b + 1, 0, :F_] = b2
+        if b + 1 < nb:
+            s1, t1 = _bn_affine(blocks[b + 1].bn1)
+            epi[2 * b + 1, 1, :F_], epi[2 * b + 1, 2, :F_] = s1, t1
+    # fc1: [A+1, F*H*W] with column index c*HW + pos  ->  Wfc'[o][pos*64 + c]
+    HW = H * W
+    wfc = net.fc1.weight.detach().double().numpy().reshape(A + 1, F_, HW)
+    n_ot = (A + 1 + 15) // 16
+    dense = np.zeros((n_ot * 16, HW, XOUT_C), dtype=np.float64)
+    dense[:A + 1, :, :F_] = wfc.transpose(0, 2, 1)
+    dense = dense.reshape(n_ot * 16, HW * XOUT_C)
+    ksteps_fc = HW * XOUT_C // 32
+    lane = np.arange(64)
+    fc_w = np.zeros((n_ot, ksteps_fc, 64, 8), dtype=np.float16)
+    kidx = (32 * np.arange(ksteps_fc)[:, None, None] + 8 * (lane >> 4)[None, :, None] + np.arange(8)[None, None, :])
+    for ot in range(n_ot):
+        rows = (16 * ot + (lane & 15))[None, :, None]
+        fc_w[ot] = dense[rows, kidx].astype(np.float16)
+    fc_b = np.zeros(n_ot * 16, dtype=np.float32)
+    fc_b[:A + 1] = net.fc1.bias.detach().numpy()
+    return {"conv_w": conv_w, "conv_epi": epi, "in_affine": in_affine, "fc_w": fc_w.view(np.uint16), "fc_b": fc_b,
+            "rows": H, "cols": W, "in_planes": cin0, "n_filters": F_, "n_blocks": nb, "num_actions": A}
+
+
+def emulate_forward(packed, obs, round_fp16=True):
+    """Numpy restatement of what az_net.hip does with the PACKED buffers (same group/tap/cell maps, same
+    fold, optional fp16 rounding of the MFMA operands) — validates the packing on a CPU-only box."""
+    H, W, A, nb = packed["rows"], packed["cols"], packed["num_actions"], packed["n_blocks"]
+    B = obs.shape[0]
+    cells = (H + 2) * (W + 1) + 1
+    rnd = (lambda a: a.astype(np.float16).astype(np.float32)) if round_fp16 else (lambda a: a.astype(np.float32))
+    lane = np.arange(64)
+
+    def unpack(cw):  # [16,4,64,8] -> dense [co 64][group 64][j 8]
+        w = cw.view(np.float16).astype(np.float32)
+        dense = np.zeros((64, NGROUPS, 8), dtype=np.float32)
+        for ks in range(KSTEPS):
+            for mt in range(4):
+                dense[16 * mt + (lane & 15), 4 * ks + (lane >> 4), :] = w[ks, mt]
+        return dense
+
+    def cell_of(y, x):
+        return (y + 1) * (W + 1) + (x + 1)
+
+    x0 = np.zeros((B, cells, 8), dtype=np.float32)
+    act = np.zeros((B, cells, CPAD), dtype=np.float32)
+    s_in, t_in = packed["in_affine"]
+    for y in range(H):
+        for x in range(W):
+            v = obs[:, :, y, x].astype(np.float32)
+            x0[:, cell_of(y, x), :v.shape[1]] = rnd(v)
+            a = s_in[None, :v.shape[1]] * v + t_in[None, :v.shape[1]]
+            act[:, cell_of(y, x), :v.shape[1]] = rnd(np.where(a > 0, a, LRELU * a))
+    xres = np.zeros((B, H * W, 64), dtype=np.float32)
+    for conv in range(2 * nb):
+        dense = unpack(packed["conv_w"][conv])
+        acc = np.zeros((B, H * W, 64), dtype=np.float32)
+        for y in range(H):
+            for x in range(W):
+                n = y * W + x
+                for g in range(NGROUPS):
+                    if g < 63:
+                        tap, c8 = divmod(g, 7)
+                        dy, dx = tap // 3 - 1, tap % 3 - 1
+                        src = act[:, cell_of(y, x) + dy * (W + 1) + dx, 8 * c8:8 * c8 + 8]
+                    else:
+                        src = x0[:, cell_of(y, x), :]
+                    acc[:, n, :] += src @ dense[:, g, :].T
+        bias, scale, shift = packed["conv_epi"][conv]
+        if conv % 2 == 0:
+            u = acc + bias[None, None, :]
+            u = rnd(np.where(u > 0, u, LRELU * u))
+            for y in range(H):
+                for x in range(W):
+                    act[:, cell_of(y, x), :] = u[:, y * W + x, :CPAD]
+        else:
+            xres = xres + acc + bias[None, None, :]
+            if conv != 2 * nb - 1:
+                a = scale[None, None, :] * xres + shift[None, None, :]
+                a = rnd(np.where(a > 0, a, LRELU * a))
+                for y in range(H):
+                    for x in range(W):
+                        act[:, cell_of(y, x), :] = a[:, y * W + x, :CPAD]
+    tower = rnd(xres)  # [B][pos][64]
+    fcw = packed["fc_w"].view(np.float16).astype(np.float32)  # [ot][ks][lane][8]
+    n_ot, ksn = fcw.shape[0], fcw.shape[1]
+    dense_fc = np.zeros((n_ot * 16, ksn * 32), dtype=np.float32)
+    for ot in range(n_ot):
+        for ks in range(ksn):
+            for q in range(4):
+                dense_fc[16 * ot + np.arange(16), 32 * ks + 8 * q:32 * ks + 8 * q + 8] = fcw[ot, ks, 16 * q:16 * q + 16, :]
+    logits = tower.reshape(B, -1) @ dense_fc.T + packed["fc_b"][None, :]
+    lp = logits[:, :A]
+    e = np.exp(lp - lp.max(1, keepdims=True))
+    return e / e.sum(1, keepdims=True), np.tanh(logits[:, A]), tower
+
+
+class FusedNet:
+    """Device handle: az_net_create / az_net_forward.  Call signature matches engine.DeviceEvaluator:
+    evaluator(obs, priors_out, values_out)."""
+
+    def __init__(self, net, device, max_boards=4096):
+        from . import _lib
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("FusedNet needs a HIP device; there is no CPU path")
+        self.device_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", self.device_index)
+        self.packed = pack_net(net.cpu() if next(net.parameters()).is_cuda else net)
+        p = self.packed
+        d = _lib.AzNetDesc()
+        d.struct_size = C.sizeof(_lib.AzNetDesc)
+        d.rows, d.cols, d.in_planes = p["rows"], p["cols"], p["in_planes"]
+        d.n_filters, d.n_blocks, d.num_actions = p["n_filters"], p["n_blocks"], p["num_actions"]
+        d.device = self.device_index
+        self._keep = [np.ascontiguousarray(p[k]) for k in ("conv_w", "conv_epi", "in_affine", "fc_w", "fc_b")]
+        d.conv_w = self._keep[0].ctypes.data_as(C.POINTER(C.c_uint16))
+        d.conv_epi = self._keep[1].ctypes.data_as(C.POINTER(C.c_float))
+        d.in_affine = self._keep[2].ctypes.data_as(C.POINTER(C.c_float))
+        d.fc_w = self._keep[3].ctypes.data_as(C.POINTER(C.c_uint16))
+        d.fc_b = self._keep[4].ctypes.data_as(C.POINTER(C.c_float))
+        self._h = C.c_void_p()
+        rc = self.lib.az_net_create(C.byref(d), C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError("az_net_create failed (%d): %s" % (rc, self.lib.az_net_last_error(None).decode()))
+        self._check(self.lib.az_net_reserve(self._h, int(max_boards)))
+        self.max_boards = int(max_boards)
+        self.A = p["num_actions"]
+        self.obs_shape = (p["in_planes"], p["rows"], p["cols"])
+
+    def _check(self, rc):
+        if rc < 0:
+            raise RuntimeError("fused net call failed (%d): %s" % (rc, self.lib.az_net_last_error(self._h).decode()))
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.az_net_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __call__(self, obs, priors_out, values_out):
+        n = obs.shape[0]
+        for t, shape in ((obs, (n,) + self.obs_shape), (priors_out, (n, self.A)), (values_out, (n,))):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device or tuple(t.shape) != shape:
+                raise RuntimeError("fused net: expected contiguous float32 %s on %s, got %s %s on %s"
+                                   % (shape, self.device, t.dtype, tuple(t.shape), t.device))
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._check(self.lib.az_net_forward(self._h, C.c_void_p(obs.data_ptr()), C.c_void_p(priors_out.data_ptr()),
+                                            C.c_void_p(values_out.data_ptr()), n, stream))
+
+    def forward(self, obs):
+        pri = torch.empty((obs.shape[0], self.A), dtype=torch.float32, device=self.device)
+        val = torch.empty((obs.shape[0],), dtype=torch.float32, device=self.device)
+        self(obs, pri, val)
+        return pri, val
+
+    def read_tower(self, n_boards):
+        out = np.zeros((n_boards, self.packed["rows"] * self.packed["cols"], XOUT_C), dtype=np.float32)
+        self._check(self.lib.az_net_read_tower(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), n_boards))
+        return out

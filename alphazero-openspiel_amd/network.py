@@ -82,7 +82,7 @@ def net_from_state_dict(sd, state_shape, num_distinct_actions):
     n_filters = sd["resblock1.conv1.weight"].shape[0]
     net = Net(state_shape, num_distinct_actions, n_blocks=n_blocks, n_filters=n_filters)
     net.load_state_dict(sd)
-    return net
+    return net.eval()  # inference use: BatchNorm on running statistics (train.py:89,154)
 
 
 def load_npz_checkpoint(path, state_shape, num_distinct_actions):

@@ -101,8 +101,9 @@ def main():
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--blocks", type=int, default=10)
     ap.add_argument("--filters", type=int, default=50)
-    ap.add_argument("--net", default="torch", choices=["torch"])
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "bf16"])
+    ap.add_argument("--net", default="fused", choices=["fused", "torch"],
+                    help="fused = csrc/az_net.hip MFMA tower (fp16 operands, fp32 accumulate); torch = nn.Module under PyTorch-ROCm")
+    ap.add_argument("--dtype", default=None, choices=["f32", "f16", "bf16"], help="torch backend only (fused is f16)")
     ap.add_argument("--check-every", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,8 +130,14 @@ def main():
     G, S, K, Wm = args.slots, args.playouts, args.steps, args.warmup
     torch.manual_seed(args.seed)
     net = Net(game.information_state_normalized_vector_shape(), A, n_blocks=args.blocks, n_filters=args.filters)
-    tdtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
-    evaluator = E.DeviceEvaluator(net, device, dtype=tdtype)
+    if args.net == "fused":
+        from alphazero_openspiel_amd.fusednet import FusedNet
+        args.dtype = "f16"
+        evaluator = FusedNet(net.eval(), device, max_boards=G)
+    else:
+        args.dtype = args.dtype or "f32"
+        tdtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
+        evaluator = E.DeviceEvaluator(net, device, dtype=tdtype)
 
     n_total = (Wm + K + 2) * G
     eng = E.SelfPlayEngine(game, G, n_playouts=S, max_games=n_total, device=device, seed=args.seed + 7919 * rank)
@@ -247,7 +254,8 @@ def main():
             "mean_plies_per_game": plies_per_game, "mean_select_depth": d_mean, "mean_children_scanned": a_sel,
             "terminal_hit_fraction": (p1["terminal_hits"] - p0["terminal_hits"]) / max(1, sims),
             "allgather_ms": allgather_ms,
-            "roofline": {"bound": "mfma", "kernel": "PV-net forward (%s, %d boards/launch)" % (args.net, G),
+            "roofline": {"bound": "mfma", "kernel": ("az_tower_kernel + az_head_kernel" if args.net == "fused" else "torch Net.forward (MIOpen)")
+                                   + ", %d boards/launch" % G,
                          "achieved": net_tflops, "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
                          "traffic": None, "flops_per_eval": f_eval, "ms_per_launch": 1e3 * t_net,
                          "batch_fill": evals_tick / G},

@@ -1,0 +1,113 @@
+"""Fused PV-net (csrc/az_net.hip) against the plain PyTorch fp32 forward of the same weights.
+
+Floating point, so a tolerance applies (north_star: "within stochastic-sampling tolerance"): the kernel keeps
+fp16 weights/activations with fp32 accumulation and an fp32 residual stream.  Bar used here: max |dprior| <= 4e-3
+and max |dvalue| <= 8e-3 against torch fp32 on CPU; the CPU-only tests check the host-side packing with a numpy
+emulation of the kernel's data movement.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from alphazero_openspiel_amd import fusednet, games
+from alphazero_openspiel_amd.network import Net, load_npz_checkpoint, state_to_board
+
+P_TOL, V_TOL = 4e-3, 8e-3
+
+
+def _random_boards(game, n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    s = game.new_initial_state()
+    while len(out) < n:
+        if s.is_terminal():
+            s = game.new_initial_state()
+        out.append(state_to_board(s, game.information_state_normalized_vector_shape()))
+        la = s.legal_actions()
+        s.apply_action(la[rng.randint(len(la))])
+    return np.array(out, dtype=np.float32)
+
+
+def _nets():
+    c4 = games.load_game("connect_four")
+    bt6 = games.load_game("breakthrough(rows=6,columns=6)")
+    bt8 = games.load_game("breakthrough(rows=8,columns=8)")
+    torch.manual_seed(3)
+    return {
+        "c4_ckpt": (c4, load_npz_checkpoint(os.path.join(GOLDEN, "checkpoint_connect_four.npz"), [3, 6, 7], 7)),
+        "bt6_ckpt": (bt6, load_npz_checkpoint(os.path.join(GOLDEN, "checkpoint_breakthrough6.npz"), [3, 6, 6], 432)),
+        "c4_10block": (c4, Net([3, 6, 7], 7, n_blocks=10, n_filters=50).eval()),
+        "bt8_2block": (bt8, Net([3, 8, 8], 768, n_blocks=2, n_filters=50).eval()),
+        "bt5x4_3block": (games.load_game("breakthrough(rows=5,columns=4)"),
+                         Net([3, 5, 4], 240, n_blocks=3, n_filters=32).eval()),
+    }
+
+
+@pytest.mark.parametrize("tag", ["c4_ckpt", "bt6_ckpt", "c4_10block", "bt5x4_3block"])
+def test_packing_emulation_matches_torch(tag):
+    game, net = _nets()[tag]
+    boards = _random_boards(game, 5, 1)
+    with torch.no_grad():
+        p, v = net(torch.from_numpy(boards))
+    packed = fusednet.pack_net(net)
+    pe, ve, _ = fusednet.emulate_forward(packed, boards, round_fp16=True)
+    assert np.abs(pe - p.numpy()).max() <= P_TOL
+    assert np.abs(ve - v.numpy()[:, 0]).max() <= V_TOL
+
+
+def test_net_matches_reference_golden_outputs():
+    """Our Net class + the re-packed shipped checkpoints reproduce the reference Net.forward fixtures."""
+    for tag, shape, A in [("connect_four", [3, 6, 7], 7), ("breakthrough6", [3, 6, 6], 432)]:
+        net = load_npz_checkpoint(os.path.join(GOLDEN, "checkpoint_%s.npz" % tag), shape, A).eval()
+        z = np.load(os.path.join(GOLDEN, "net_forward_%s.npz" % tag))
+        with torch.no_grad():
+            p, v = net(torch.from_numpy(z["boards"].astype(np.float32)))
+        assert np.abs(p.numpy() - z["p"]).max() < 2e-5
+        assert np.abs(v.numpy() - z["v"]).max() < 2e-5
+        assert set(net.state_dict().keys()) == set(np.load(os.path.join(GOLDEN, "checkpoint_%s.npz" % tag)).files)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,n", [("c4_ckpt", 24), ("c4_ckpt", 1), ("c4_ckpt", 157), ("bt6_ckpt", 40),
+                                   ("c4_10block", 300), ("bt8_2block", 37), ("bt5x4_3block", 50)])
+def test_fused_forward_matches_torch(tag, n):
+    game, net = _nets()[tag]
+    boards = _random_boards(game, n, 7)
+    with torch.no_grad():
+        p, v = net(torch.from_numpy(boards))
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=max(n, 16))
+    obs = torch.from_numpy(boards).cuda()
+    pf, vf = fn.forward(obs)
+    torch.cuda.synchronize()
+    pf, vf = pf.cpu().numpy(), vf.cpu().numpy()
+    assert np.isfinite(pf).all() and np.isfinite(vf).all()
+    assert np.abs(pf.sum(1) - 1).max() < 1e-5
+    dp, dv = np.abs(pf - p.numpy()).max(), np.abs(vf - v.numpy()[:, 0]).max()
+    assert dp <= P_TOL and dv <= V_TOL, (dp, dv)
+    # the tower output (pre-fc residual stream) agrees with the fp16-rounding emulation of the same packing
+    if n <= 40:
+        _, _, tower = fusednet.emulate_forward(fn.packed, boards, round_fp16=True)
+        got = fn.read_tower(n)
+        scale = np.abs(tower).max() + 1e-6
+        assert np.abs(got - tower).max() / scale < 5e-3
+    # a second call with a different batch reuses the buffers
+    pf2, vf2 = fn.forward(obs[: max(1, n // 2)].contiguous())
+    torch.cuda.synchronize()
+    assert np.abs(pf2.cpu().numpy() - pf[: max(1, n // 2)]).max() < 1e-6
+    fn.close()
+
+
+@pytest.mark.gpu
+def test_fused_net_rejects_bad_arguments():
+    game, net = _nets()["c4_ckpt"]
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=8)
+    with pytest.raises(RuntimeError):
+        fn.forward(torch.zeros(9, 4, 6, 7, device="cuda"))      # more boards than reserved
+    with pytest.raises(RuntimeError):
+        fn.forward(torch.zeros(4, 4, 6, 7, device="cuda", dtype=torch.float16))
+    with pytest.raises(ValueError):
+        fusednet.pack_net(Net([3, 6, 7], 7, n_blocks=2, n_filters=64))  # > 56 filters
+    fn.close()
