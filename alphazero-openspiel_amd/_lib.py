@@ -55,7 +55,8 @@ class AzNetDesc(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("in_planes", C.c_int32),
                 ("n_filters", C.c_int32), ("n_blocks", C.c_int32), ("num_actions", C.c_int32), ("device", C.c_int32),
                 ("conv_w", C.POINTER(C.c_uint16)), ("conv_epi", C.POINTER(C.c_float)),
-                ("in_affine", C.POINTER(C.c_float)), ("fc_w", C.POINTER(C.c_uint16)), ("fc_b", C.POINTER(C.c_float))]
+                ("in_affine", C.POINTER(C.c_float)), ("skip_w", C.POINTER(C.c_float)),
+                ("fc_w", C.POINTER(C.c_uint16)), ("fc_b", C.POINTER(C.c_float))]
 
 
 # every symbol include/az_engine.h and include/az_net.h declare: (name, restype, argtypes)

@@ -28,96 +28,112 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define CELL_B (AZ_NET_CPAD * 2) // 112 bytes per cell
-#define X0_B 16                  // raw input planes: 8 fp16 per cell
-#define CHUNK_KS 4               // k-steps per weight chunk
-#define CHUNK_B (CHUNK_KS * 4 * 64 * 16)
+#define OCT_B 16 // one cell of one channel-octet plane: 8 fp16
+#define N_OCT 7  // 56 channels
 #define WAVES 4
 
 struct TowerParams {
-    int H, W, HW, cells, cin, n_convs, n_boards, bpw, zero_b;
-    int off_zero, off_x0, off_act; // LDS byte offsets (weights buffers at 0 and CHUNK_B)
+    int H, W, HW, cells, cin, n_convs, n_boards, bpw;
+    int rcells;  // cells per wave region (bpw boards + zero pad), multiple of 16
+    int zcell;   // a cell whose whole 3x3 neighbourhood is never written (reads of padding columns land here)
+    int off_act; // LDS byte offset of the activation planes (weight buffers come first)
     const _Float16 *conv_w;
     const float *epi;
+    const float *skip_w; // [64][4]
     float in_scale[8], in_shift[8];
     const float *obs;
     _Float16 *xout;
 };
 
-__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.01f * v; }
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.01f * v); }
 
-template <int NT>
+__device__ __forceinline__ half4 lrelu_h4(half4 h) { return __builtin_elementwise_max(h, h * (_Float16)0.01f); }
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// LDS fragment read the compiler does not track (no automatic s_waitcnt): waited for by hand in the k-loop
+__device__ __forceinline__ void lds_read128(half8 &dst, unsigned lds_byte_addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_byte_addr));
+}
+
+// LDS image of one wave: 7 channel-octet planes [rcells][8 fp16]; plane stride is a multiple of 256 B, so the 16
+// lanes of a ds_read_b128 group (8 columns of octet c, 8 columns of octet c+1, consecutive cells) hit 16 different
+// 16-byte bank slots: conflict-free.  cell = board*cells + (y+1)*(W+1) + (x+1); halo cells stay zero.
+template <int NT, int CK>
 __global__ __launch_bounds__(256, 1) void az_tower_kernel(TowerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int CHUNK_B = CK * 4 * 64 * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l15 = lane & 15;
     const int W1 = p.W + 1;
+    const int plane_b = p.rcells * OCT_B, region_b = N_OCT * plane_b;
     const int board0 = (blockIdx.x * WAVES + wave) * p.bpw; // first global board of this wave
+    const int region = p.off_act + wave * region_b;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
 
-    // ---- zero the wave's private images and (wave 0) the shared zero region ---------------------------
-    {
-        const int act_b = p.bpw * p.cells * CELL_B, x0_b = p.bpw * p.cells * X0_B;
+    { // zero the wave's private planes (halo + padding must read as 0)
         uint4 z = {0, 0, 0, 0};
-        unsigned char *act = lds + p.off_act + wave * act_b, *x0 = lds + p.off_x0 + wave * x0_b;
-        for (int i = lane * 16; i < act_b; i += 64 * 16) *(uint4 *)(act + i) = z;
-        for (int i = lane * 16; i < x0_b; i += 64 * 16) *(uint4 *)(x0 + i) = z;
-        if (wave == 0)
-            for (int i = lane * 16; i < p.zero_b; i += 64 * 16) *(uint4 *)(lds + p.off_zero + i) = z;
+        for (int i = lane * 16; i < region_b; i += 64 * 16) *(uint4 *)(lds + region + i) = z;
     }
-    // ---- per-lane address tables ------------------------------------------------------------------------
-    int pos_addr[NT], x0_addr[NT], grow[NT]; // LDS byte offsets of column n's cell; global row of xout (or -1)
-    const int zero_mid = p.off_zero + ((p.zero_b / 2) & ~15);
+    // ---- per-lane tables: column n = 16*nt + l15 of this wave -------------------------------------------
+    int pos_addr[NT], grow[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         int n = nt * 16 + l15;
         int b = n / p.HW, pos = n - b * p.HW;
         bool ok = (b < p.bpw) && (board0 + b < p.n_boards);
         int y = pos / p.W, x = pos - y * p.W;
-        int cell = (y + 1) * W1 + (x + 1);
-        pos_addr[nt] = ok ? p.off_act + ((wave * p.bpw + b) * p.cells + cell) * CELL_B : zero_mid;
-        x0_addr[nt] = ok ? p.off_x0 + ((wave * p.bpw + b) * p.cells + cell) * X0_B : zero_mid;
+        int cell = b * p.cells + (y + 1) * W1 + (x + 1);
+        pos_addr[nt] = region + (ok ? cell : p.zcell) * OCT_B;
         grow[nt] = ok ? (board0 + b) * p.HW + pos : -1;
     }
-    int koff[AZ_NET_KSTEPS]; // byte offset of (tap, channel octet) for this lane's k-group in each k-step
+    int koff[AZ_NET_KSTEPS]; // byte offset (tap shift + octet plane) of this lane's k-group in each k-step
 #pragma unroll
     for (int ks = 0; ks < AZ_NET_KSTEPS; ks++) {
         int g = 4 * ks + q;
         int tap = g / 7, c8 = g - tap * 7;
         int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        koff[ks] = (dy * W1 + dx) * CELL_B + c8 * 16;
-    }
-    // ---- input prologue: raw planes -> x0 image; a = lrelu(bn1(x0)) -> channels 0..cin-1 of the act image --
-    for (int b = 0; b < p.bpw; b++) {
-        int gb = board0 + b;
-        if (gb >= p.n_boards) break;
-        for (int pos = lane; pos < p.HW; pos += 64) {
-            int y = pos / p.W, x = pos - y * p.W;
-            int cell = (y + 1) * W1 + (x + 1);
-            half8 raw = {0, 0, 0, 0, 0, 0, 0, 0};
-            half4 a4 = {0, 0, 0, 0};
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                if (c < p.cin) {
-                    float v = p.obs[((size_t)gb * p.cin + c) * p.HW + pos];
-                    raw[c] = (_Float16)v;
-                    a4[c] = (_Float16)lrelu(p.in_scale[c] * v + p.in_shift[c]);
-                }
-            *(half8 *)(lds + p.off_x0 + ((wave * p.bpw + b) * p.cells + cell) * X0_B) = raw;
-            *(half4 *)(lds + p.off_act + ((wave * p.bpw + b) * p.cells + cell) * CELL_B) = a4;
-        }
+        koff[ks] = g == 63 ? 0 : (dy * W1 + dx) * OCT_B + c8 * plane_b; // group 63: zero weights, any finite data
     }
 
     f32x4 acc[4][NT], xres[4][NT];
+    // ---- prologue: a = lrelu(bn1(x0)) -> octet 0; block-1 skip conv3(x0) in fp32 -> residual stream --------
+    {
+        f32x4 sw[4][4]; // skip weights of this lane's 16 output channels: [mt][r] -> 4 input planes
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sw[mt][r] = *(const f32x4 *)(p.skip_w + (16 * mt + 4 * q + r) * 4);
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
-            acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            xres[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (grow[nt] >= 0) {
+                int gb = grow[nt] / p.HW, pos = grow[nt] - gb * p.HW;
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (c < p.cin) v[c] = p.obs[((size_t)gb * p.cin + c) * p.HW + pos];
+                if (q == 0) {
+                    half4 a4;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) a4[c] = c < p.cin ? (_Float16)lrelu(p.in_scale[c] * v[c] + p.in_shift[c]) : (_Float16)0;
+                    *(half4 *)(lds + pos_addr[nt]) = a4;
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                f32x4 x;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    x[r] = sw[mt][r][0] * v[0] + sw[mt][r][1] * v[1] + sw[mt][r][2] * v[2] + sw[mt][r][3] * v[3];
+                xres[mt][nt] = x;
+                acc[mt][nt] = *(const f32x4 *)(p.epi + 16 * mt + 4 * q); // bias of conv 0
+            }
         }
+    }
 
-    // ---- weight stream: chunk c of 16 KiB -> buffer c&1, by LDS-DMA -----------------------------------
-    const int n_chunks = p.n_convs * (AZ_NET_KSTEPS / CHUNK_KS);
+    // ---- weight stream: chunk c (CK k-steps) -> buffer c&1, by LDS-DMA (global_load_lds, 16 B/lane) ----------
+    const int n_chunks = p.n_convs * (AZ_NET_KSTEPS / CK);
     auto issue_chunk = [&](int c) {
         const unsigned char *src = (const unsigned char *)p.conv_w + (size_t)c * CHUNK_B;
         unsigned char *dst = lds + (c & 1) * CHUNK_B;
@@ -133,56 +149,81 @@ __global__ __launch_bounds__(256, 1) void az_tower_kernel(TowerParams p) {
     int chunk = 0;
     for (int conv = 0; conv < p.n_convs; conv++) {
 #pragma unroll
-        for (int part = 0; part < AZ_NET_KSTEPS / CHUNK_KS; part++, chunk++) {
-            __syncthreads(); // chunk's DMA landed for every wave (vmcnt(0) precedes the barrier); other buffer is free
+        for (int part = 0; part < AZ_NET_KSTEPS / CK; part++, chunk++) {
+            __syncthreads(); // this chunk's DMA has landed for every wave (vmcnt(0) precedes the barrier); other buffer is free
             if (chunk + 1 < n_chunks) issue_chunk(chunk + 1);
-            const unsigned char *wb = lds + (chunk & 1) * CHUNK_B;
+            // Fragment reads are inline asm so that the compiler neither sinks them next to their first use nor
+            // inserts its own lgkmcnt(0) (left alone it waits every 8 MFMAs: 34 % MFMA utilisation).  Order:
+            //   wait(all of k-step ksl) ; for each read of k-step ksl+1: {ds_read ; MFMA of ksl} ; remaining MFMAs
+            // so a read has most of an MFMA block (16 cycles per MFMA) to land before the next wait.
+            const unsigned wbl = lds_base + (chunk & 1) * CHUNK_B + lane * 16;
+            half8 a[2][4], b[2][NT];
 #pragma unroll
-            for (int ksl = 0; ksl < CHUNK_KS; ksl++) {
-                const int ks = part * CHUNK_KS + ksl;
-                half8 a[4];
+            for (int mt = 0; mt < 4; mt++) lds_read128(a[0][mt], wbl + mt * 1024);
+            {
+                int ko = opaque(koff[part * CK]); // keep pos_addr + koff out of LICM's hands (it would hoist NT*16 sums)
 #pragma unroll
-                for (int mt = 0; mt < 4; mt++) a[mt] = *(const half8 *)(wb + ((ksl * 4 + mt) * 64 + lane) * 16);
+                for (int nt = 0; nt < NT; nt++) lds_read128(b[0][nt], lds_base + pos_addr[nt] + ko);
+            }
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
-                    int addr = pos_addr[nt] + koff[ks];
-                    if (ks == AZ_NET_KSTEPS - 1 && q == 3) addr = x0_addr[nt]; // group 63: raw input planes
-                    half8 b = *(const half8 *)(lds + addr);
+            for (int ksl = 0; ksl < CK; ksl++) {
+                const int cur = ksl & 1, nxt = cur ^ 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                int issued = 0; // MFMAs of this k-step issued so far, in (nt, mt) order
+                if (ksl + 1 < CK) {
+                    const int ko = opaque(koff[part * CK + ksl + 1]);
 #pragma unroll
-                    for (int mt = 0; mt < 4; mt++)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b, acc[mt][nt], 0, 0, 0);
+                    for (int i = 0; i < NT + 4; i++) {
+                        if (i < 4) lds_read128(a[nxt][i], wbl + ((ksl + 1) * 4 + i) * 1024);
+                        else lds_read128(b[nxt][i - 4], lds_base + pos_addr[i - 4] + ko);
+                        {
+                            const int nt = issued >> 2, mt = issued & 3;
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
+                            issued++;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+#pragma unroll
+                for (int j = 0; j < 4 * NT; j++)
+                    if (j >= issued) {
+                        const int nt = j >> 2, mt = j & 3;
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- epilogue of this conv (the wave's own boards only: no barrier needed) ------------------------
+        // The accumulators were initialised with this conv's bias, so: conv1: u = lrelu(acc); conv2: x += acc,
+        // a = lrelu(scale*x + shift).  LeakyReLU runs on the packed fp16 values (v_pk_mul_f16 + v_pk_max_f16).
         const float *ep = p.epi + (size_t)conv * 3 * 64;
         const bool is_conv2 = conv & 1, last = conv == p.n_convs - 1;
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) {
             const int co0 = 16 * mt + 4 * q;
-            f32x4 bias = *(const f32x4 *)(ep + co0);
+            const int woff = (2 * mt + (q >> 1)) * plane_b + (q & 1) * 8; // octet plane + half of the octet
+            const bool wr = (2 * mt + (q >> 1)) < N_OCT;
             f32x4 sc = *(const f32x4 *)(ep + 64 + co0), sh = *(const f32x4 *)(ep + 128 + co0);
+            f32x4 next_bias = last ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4 *)(ep + 192 + co0);
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
-                f32x4 v = acc[mt][nt] + bias;
-                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 v = acc[mt][nt];
+                acc[mt][nt] = next_bias;
                 half4 o;
-                if (!is_conv2) { // u = lrelu(conv1'(a) + b1')
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (_Float16)lrelu(v[r]);
-                } else { // x += conv2(u) + b2 ; a = lrelu(bn1_next(x))
+                if (!is_conv2) {
+                    o = lrelu_h4(__builtin_convertvector(v, half4));
+                } else {
                     f32x4 xv = xres[mt][nt] + v;
                     xres[mt][nt] = xv;
                     if (last) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) o[r] = (_Float16)xv[r];
+                        o = __builtin_convertvector(xv, half4);
                         if (grow[nt] >= 0) *(half4 *)(p.xout + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = o;
                         continue;
                     }
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (_Float16)lrelu(sc[r] * xv[r] + sh[r]);
+                    o = lrelu_h4(__builtin_convertvector(sc * xv + sh, half4));
                 }
-                if (grow[nt] >= 0 && co0 < AZ_NET_CPAD) *(half4 *)(lds + pos_addr[nt] + co0 * 2) = o;
+                if (wr && grow[nt] >= 0) *(half4 *)(lds + pos_addr[nt] + woff) = o;
             }
         }
     }
@@ -264,10 +305,10 @@ struct az_net {
     az_net_desc d;
     std::string err;
     _Float16 *conv_w = nullptr, *fc_w = nullptr, *xout = nullptr;
-    float *epi = nullptr, *fc_b = nullptr;
+    float *epi = nullptr, *fc_b = nullptr, *skip_w = nullptr;
     float in_affine[16];
     int max_boards = 0;
-    int bpw = 0, nt = 0, cells = 0, zero_b = 0, lds_tower = 0, lds_head = 0, n_ot = 0;
+    int bpw_max = 0, cells = 0, lds_head = 0, n_ot = 0;
 };
 static std::string g_net_err;
 
@@ -290,11 +331,27 @@ extern "C" int az_net_destroy(az_net *n) {
     (void)hipFree(n->xout);
     (void)hipFree(n->epi);
     (void)hipFree(n->fc_b);
+    (void)hipFree(n->skip_w);
     delete n;
     return AZ_OK;
 }
 
-static int tower_lds_bytes(int bpw, int cells, int zero_b) { return 2 * CHUNK_B + zero_b + WAVES * bpw * cells * (CELL_B + X0_B); }
+// geometry of one launch for a given boards-per-wave
+struct TowerGeom {
+    int bpw, nt, ck, rcells, zcell, lds;
+};
+static TowerGeom tower_geom(int bpw, int H, int W) {
+    TowerGeom g;
+    int cells = (H + 2) * (W + 1) + 1, zpad = 2 * (W + 2) + 1;
+    g.bpw = bpw;
+    g.nt = (bpw * H * W + 15) / 16;
+    g.rcells = (bpw * cells + zpad + 15) & ~15;
+    g.zcell = bpw * cells + (W + 2);
+    int act = WAVES * N_OCT * g.rcells * OCT_B;
+    g.ck = (act + 2 * 8 * 4096 <= 160 * 1024 && g.nt <= 7) ? 8 : 4; // 32 KiB weight chunks when LDS and registers allow
+    g.lds = act + 2 * g.ck * 4096;
+    return g;
+}
 
 extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     if (!desc || !out) {
@@ -309,7 +366,7 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     const az_net_desc &d = *desc;
     if (d.rows < 3 || d.cols < 3 || d.rows * d.cols > 64 || d.in_planes < 1 || d.in_planes > 4 || d.n_filters < 1 ||
         d.n_filters > AZ_NET_CPAD || d.n_blocks < 1 || d.num_actions < 1 || !d.conv_w || !d.conv_epi || !d.in_affine ||
-        !d.fc_w || !d.fc_b) {
+        !d.skip_w || !d.fc_w || !d.fc_b) {
         g_net_err = "bad net description (need 3<=rows,cols, rows*cols<=64, in_planes<=4, n_filters<=56, packed buffers)";
         return AZ_E_INVALID;
     }
@@ -318,12 +375,11 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     memcpy(n->in_affine, d.in_affine, sizeof n->in_affine);
     const int HW = d.rows * d.cols;
     n->cells = (d.rows + 2) * (d.cols + 1) + 1;
-    n->zero_b = (2 * (d.cols + 2) * CELL_B + 256 + 15) & ~15;
-    // boards per wave: fill up to 9 column tiles (144 columns) within the 160 KiB LDS
+    // boards per wave: up to 8 column tiles (128 columns; 9 would spill registers) within the 160 KiB LDS
     int best = 0;
     for (int bpw = 1; bpw <= 8; bpw++) {
-        int nt = (bpw * HW + 15) / 16;
-        if (nt > 9 || tower_lds_bytes(bpw, n->cells, n->zero_b) > 160 * 1024) break;
+        TowerGeom g = tower_geom(bpw, d.rows, d.cols);
+        if (g.nt > 8 || g.lds > 160 * 1024) break;
         best = bpw;
     }
     if (!best) {
@@ -331,10 +387,7 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
         delete n;
         return AZ_E_INVALID;
     }
-    n->bpw = best;
-    n->nt = (best * HW + 15) / 16;
-    if (n->nt < 6) n->nt = 6;
-    n->lds_tower = tower_lds_bytes(best, n->cells, n->zero_b);
+    n->bpw_max = best;
     n->n_ot = (d.num_actions + 1 + 15) / 16;
     n->lds_head = 4 * OTG * 64 * 16 + 16 * n->n_ot * 16 * 4;
     hipError_t s = hipSetDevice(d.device);
@@ -357,6 +410,7 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     up((void **)&n->epi, d.conv_epi, ep);
     up((void **)&n->fc_w, d.fc_w, fw);
     up((void **)&n->fc_b, d.fc_b, fb);
+    up((void **)&n->skip_w, d.skip_w, 64 * 4 * sizeof(float));
     if (rc != AZ_OK) {
         az_net_destroy(n);
         return rc;
@@ -364,6 +418,7 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     n->d.conv_w = nullptr; // host pointers are not kept
     n->d.conv_epi = nullptr;
     n->d.in_affine = nullptr;
+    n->d.skip_w = nullptr;
     n->d.fc_w = nullptr;
     n->d.fc_b = nullptr;
     *out = n;
@@ -382,15 +437,18 @@ extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
     return AZ_OK;
 }
 
-template <int NT> static hipError_t launch_tower(const az_net *n, const TowerParams &tp, int grid, hipStream_t st) {
+template <int NT, int CK> static hipError_t launch_tower(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
     static bool attr_set[16] = {false};
     if (!attr_set[n->d.device & 15]) {
-        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (s != hipSuccess) return s;
         attr_set[n->d.device & 15] = true;
     }
-    hipLaunchKernelGGL((az_tower_kernel<NT>), dim3(grid), dim3(256), n->lds_tower, st, tp);
+    hipLaunchKernelGGL((az_tower_kernel<NT, CK>), dim3(grid), dim3(256), lds, st, tp);
     return hipGetLastError();
+}
+template <int NT> static hipError_t launch_tower_ck(const az_net *n, const TowerParams &tp, int grid, const TowerGeom &g, hipStream_t st) {
+    return g.ck == 8 ? launch_tower<NT, 8>(n, tp, grid, g.lds, st) : launch_tower<NT, 4>(n, tp, grid, g.lds, st);
 }
 
 extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float *values, int32_t n_boards, void *stream) {
@@ -400,6 +458,21 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         return AZ_E_STATE;
     }
     hipStream_t st = (hipStream_t)stream;
+    // boards per wave: one workgroup (4 waves) per CU is resident, a launch runs in ceil(WGs / 256) rounds and a
+    // round costs ~ (column tiles + fixed part): pick the bpw that minimises rounds x tiles for THIS batch size.
+    TowerGeom g = tower_geom(1, n->d.rows, n->d.cols);
+    {
+        long best_cost = -1;
+        for (int bpw = 1; bpw <= n->bpw_max; bpw++) {
+            TowerGeom c = tower_geom(bpw, n->d.rows, n->d.cols);
+            long wgs = (n_boards + WAVES * bpw - 1) / (WAVES * bpw);
+            long cost = ((wgs + 255) / 256) * (2 * (c.nt < 3 ? 3 : c.nt) + 1);
+            if (best_cost < 0 || cost <= best_cost) {
+                best_cost = cost;
+                g = c;
+            }
+        }
+    }
     TowerParams tp;
     tp.H = n->d.rows;
     tp.W = n->d.cols;
@@ -408,24 +481,26 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     tp.cin = n->d.in_planes;
     tp.n_convs = 2 * n->d.n_blocks;
     tp.n_boards = n_boards;
-    tp.bpw = n->bpw;
-    tp.zero_b = n->zero_b;
-    tp.off_zero = 2 * CHUNK_B;
-    tp.off_x0 = tp.off_zero + n->zero_b;
-    tp.off_act = tp.off_x0 + WAVES * n->bpw * n->cells * X0_B;
+    tp.bpw = g.bpw;
+    tp.rcells = g.rcells;
+    tp.zcell = g.zcell;
+    tp.off_act = 2 * g.ck * 4096;
     tp.conv_w = n->conv_w;
     tp.epi = n->epi;
+    tp.skip_w = n->skip_w;
     memcpy(tp.in_scale, n->in_affine, 32);
     memcpy(tp.in_shift, n->in_affine + 8, 32);
     tp.obs = obs;
     tp.xout = n->xout;
-    int per_wg = WAVES * n->bpw, grid = (n_boards + per_wg - 1) / per_wg;
+    int per_wg = WAVES * g.bpw, grid = (n_boards + per_wg - 1) / per_wg;
     hipError_t s;
-    switch (n->nt) {
-    case 6: s = launch_tower<6>(n, tp, grid, st); break;
-    case 7: s = launch_tower<7>(n, tp, grid, st); break;
-    case 8: s = launch_tower<8>(n, tp, grid, st); break;
-    default: s = launch_tower<9>(n, tp, grid, st); break;
+    switch (g.nt < 3 ? 3 : g.nt) {
+    case 3: s = launch_tower_ck<3>(n, tp, grid, g, st); break;
+    case 4: s = launch_tower_ck<4>(n, tp, grid, g, st); break;
+    case 5: s = launch_tower_ck<5>(n, tp, grid, g, st); break;
+    case 6: s = launch_tower_ck<6>(n, tp, grid, g, st); break;
+    case 7: s = launch_tower_ck<7>(n, tp, grid, g, st); break;
+    default: s = launch_tower_ck<8>(n, tp, grid, g, st); break;
     }
     if (s != hipSuccess) {
         n->err = std::string("tower launch: ") + hipGetErrorString(s);

@@ -10,8 +10,8 @@ What the kernel computes is exactly `Net.forward` in eval mode (reference networ
 
 3x3 convs are implicit GEMMs on the MFMA units: D[co][n] = sum_k Wp[co][k] * Act[k][n], n = (board, position),
 k = 64 "groups" x 8 channels: group g < 63 -> (tap, c8) = divmod(g, 7), channel = 8*c8 + j, tap -> (dy,dx) =
-(tap//3-1, tap%3-1); group 63 reads the raw input planes and carries block 1's 1x1 skip conv (conv3) —
-zero for every other conv.  So every conv is exactly 16 k-steps of 32.
+(tap//3-1, tap%3-1); group 63 is zero padding.  So every conv is exactly 16 k-steps of 32.  Block 1's 1x1 skip
+conv (conv3 on the raw planes) is not a GEMM at all: 4 input planes -> applied in fp32 into the residual stream.
 
 Weights are stored in "fragment-linear" order: for k-step ks, output tile mt, lane l, element j:
     co = 16*mt + (l & 15),  group = 4*ks + (l >> 4)
@@ -35,8 +35,8 @@ def _bn_affine(bn):
     return s.numpy(), t.numpy()
 
 
-def _pack_conv(w3x3, skip_w=None):
-    """w3x3: float64 [F, Cin, 3, 3] (already folded) -> fp16 bits [16, 4, 64, 8]; skip_w: [F, Cs] 1x1 weights."""
+def _pack_conv(w3x3):
+    """w3x3: float64 [F, Cin, 3, 3] (already folded) -> fp16 bits [16, 4, 64, 8]."""
     F_, cin = w3x3.shape[0], w3x3.shape[1]
     assert F_ <= 64 and cin <= CPAD
     dense = np.zeros((64, NGROUPS, 8), dtype=np.float64)  # [co][group][j]
@@ -47,8 +47,6 @@ def _pack_conv(w3x3, skip_w=None):
             ci = 8 * c8 + j
             if ci < cin:
                 dense[:F_, g, j] = w3x3[:, ci, ky, kx]
-    if skip_w is not None:
-        dense[:F_, 63, :skip_w.shape[1]] = skip_w
     out = np.zeros((KSTEPS, 4, 64, 8), dtype=np.float16)
     lane = np.arange(64)
     for ks in range(KSTEPS):
@@ -64,8 +62,8 @@ def pack_net(net):
     blocks = [getattr(net, "resblock%d" % (i + 1)) for i in range(getattr(net, "n_blocks", 5))]
     H, W, A = net.height, net.width, net.num_distinct_actions
     cin0 = net.num_filters_input
-    if F_ > CPAD or cin0 > 8:
-        raise ValueError("fused net supports n_filters <= %d and <= 8 input planes" % CPAD)
+    if F_ > CPAD or cin0 > 4:
+        raise ValueError("fused net supports n_filters <= %d and <= 4 input planes" % CPAD)
     nb = len(blocks)
     conv_w = np.zeros((2 * nb, KSTEPS, 4, 64, 8), dtype=np.uint16)
     epi = np.zeros((2 * nb, 3, 64), dtype=np.float32)
@@ -73,6 +71,7 @@ def pack_net(net):
     s_in, t_in = _bn_affine(blocks[0].bn1)
     in_affine = np.zeros((2, 8), dtype=np.float32)
     in_affine[0, :cin0], in_affine[1, :cin0] = s_in, t_in
+    skip_w = np.zeros((64, 4), dtype=np.float32)
     for b, blk in enumerate(blocks):
         s2, t2 = _bn_affine(blk.bn2)
         w1 = blk.conv1.weight.detach().double().numpy() * s2[:, None, None, None]
@@ -81,13 +80,14 @@ def pack_net(net):
         epi[2 * b, 0, :F_] = b1
         w2 = blk.conv2.weight.detach().double().numpy()
         b2 = blk.conv2.bias.detach().double().numpy().copy()
-        skip = None
         if blk.use_1x1conv:
             if b != 0:
                 raise ValueError("a 1x1 skip conv is only supported on the first block")
-            skip = blk.conv3.weight.detach().double().numpy()[:, :, 0, 0]
+            skip_w[:F_, :cin0] = blk.conv3.weight.detach().numpy()[:, :, 0, 0]
             b2 = b2 + blk.conv3.bias.detach().double().numpy()
-        conv_w[2 * b + 1] = _pack_conv(w2, skip)
+        elif b == 0:  # identity skip on block 1 (in_planes == n_filters)
+            skip_w[:F_, :cin0] = np.eye(F_, cin0, dtype=np.float32)
+        conv_w[2 * b + 1] = _pack_conv(w2)
         epi[2 * b + 1, 0, :F_] = b2
         if b + 1 < nb:
             s1, t1 = _bn_affine(blocks[b + 1].bn1)
@@ -108,7 +108,8 @@ def pack_net(net):
         fc_w[ot] = dense[rows, kidx].astype(np.float16)
     fc_b = np.zeros(n_ot * 16, dtype=np.float32)
     fc_b[:A + 1] = net.fc1.bias.detach().numpy()
-    return {"conv_w": conv_w, "conv_epi": epi, "in_affine": in_affine, "fc_w": fc_w.view(np.uint16), "fc_b": fc_b,
+    return {"conv_w": conv_w, "conv_epi": epi, "in_affine": in_affine, "skip_w": skip_w,
+            "fc_w": fc_w.view(np.uint16), "fc_b": fc_b,
             "rows": H, "cols": W, "in_planes": cin0, "n_filters": F_, "n_blocks": nb, "num_actions": A}
 
 
@@ -132,29 +133,25 @@ def emulate_forward(packed, obs, round_fp16=True):
     def cell_of(y, x):
         return (y + 1) * (W + 1) + (x + 1)
 
-    x0 = np.zeros((B, cells, 8), dtype=np.float32)
     act = np.zeros((B, cells, CPAD), dtype=np.float32)
+    xres = np.zeros((B, H * W, 64), dtype=np.float32)
     s_in, t_in = packed["in_affine"]
     for y in range(H):
         for x in range(W):
             v = obs[:, :, y, x].astype(np.float32)
-            x0[:, cell_of(y, x), :v.shape[1]] = rnd(v)
+            xres[:, y * W + x, :] = v @ packed["skip_w"][:, :v.shape[1]].T  # block-1 skip path, fp32
             a = s_in[None, :v.shape[1]] * v + t_in[None, :v.shape[1]]
             act[:, cell_of(y, x), :v.shape[1]] = rnd(np.where(a > 0, a, LRELU * a))
-    xres = np.zeros((B, H * W, 64), dtype=np.float32)
     for conv in range(2 * nb):
         dense = unpack(packed["conv_w"][conv])
         acc = np.zeros((B, H * W, 64), dtype=np.float32)
         for y in range(H):
             for x in range(W):
                 n = y * W + x
-                for g in range(NGROUPS):
-                    if g < 63:
-                        tap, c8 = divmod(g, 7)
-                        dy, dx = tap // 3 - 1, tap % 3 - 1
-                        src = act[:, cell_of(y, x) + dy * (W + 1) + dx, 8 * c8:8 * c8 + 8]
-                    else:
-                        src = x0[:, cell_of(y, x), :]
+                for g in range(63):
+                    tap, c8 = divmod(g, 7)
+                    dy, dx = tap // 3 - 1, tap % 3 - 1
+                    src = act[:, cell_of(y, x) + dy * (W + 1) + dx, 8 * c8:8 * c8 + 8]
                     acc[:, n, :] += src @ dense[:, g, :].T
         bias, scale, shift = packed["conv_epi"][conv]
         if conv % 2 == 0:
@@ -204,12 +201,13 @@ class FusedNet:
         d.rows, d.cols, d.in_planes = p["rows"], p["cols"], p["in_planes"]
         d.n_filters, d.n_blocks, d.num_actions = p["n_filters"], p["n_blocks"], p["num_actions"]
         d.device = self.device_index
-        self._keep = [np.ascontiguousarray(p[k]) for k in ("conv_w", "conv_epi", "in_affine", "fc_w", "fc_b")]
+        self._keep = [np.ascontiguousarray(p[k]) for k in ("conv_w", "conv_epi", "in_affine", "fc_w", "fc_b", "skip_w")]
         d.conv_w = self._keep[0].ctypes.data_as(C.POINTER(C.c_uint16))
         d.conv_epi = self._keep[1].ctypes.data_as(C.POINTER(C.c_float))
         d.in_affine = self._keep[2].ctypes.data_as(C.POINTER(C.c_float))
         d.fc_w = self._keep[3].ctypes.data_as(C.POINTER(C.c_uint16))
         d.fc_b = self._keep[4].ctypes.data_as(C.POINTER(C.c_float))
+        d.skip_w = self._keep[5].ctypes.data_as(C.POINTER(C.c_float))
         self._h = C.c_void_p()
         rc = self.lib.az_net_create(C.byref(d), C.byref(self._h))
         if rc != 0:

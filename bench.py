@@ -105,6 +105,8 @@ def main():
                     help="fused = csrc/az_net.hip MFMA tower (fp16 operands, fp32 accumulate); torch = nn.Module under PyTorch-ROCm")
     ap.add_argument("--dtype", default=None, choices=["f32", "f16", "bf16"], help="torch backend only (fused is f16)")
     ap.add_argument("--check-every", type=int, default=32)
+    ap.add_argument("--nodes-per-slot", type=int, default=0, help="node-pool capacity per slot (0 = engine default)")
+    ap.add_argument("--max-sims-per-tick", type=int, default=0, help="NN-free playouts a slot may chain per tick (0 = default)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
@@ -140,7 +142,8 @@ def main():
         evaluator = E.DeviceEvaluator(net, device, dtype=tdtype)
 
     n_total = (Wm + K + 2) * G
-    eng = E.SelfPlayEngine(game, G, n_playouts=S, max_games=n_total, device=device, seed=args.seed + 7919 * rank)
+    eng = E.SelfPlayEngine(game, G, n_playouts=S, max_games=n_total, device=device, seed=args.seed + 7919 * rank,
+                           nodes_per_slot=args.nodes_per_slot, max_sims_per_tick=args.max_sims_per_tick)
     eng.reset(n_total)
     obs, pri, val = eng.alloc_io()
 
@@ -253,7 +256,8 @@ def main():
             "games_timed": games_all, "ticks_timed_rank0": ticks,
             "mean_plies_per_game": plies_per_game, "mean_select_depth": d_mean, "mean_children_scanned": a_sel,
             "terminal_hit_fraction": (p1["terminal_hits"] - p0["terminal_hits"]) / max(1, sims),
-            "allgather_ms": allgather_ms,
+            "allgather_ms": allgather_ms, "compactions": p1["compactions"] - p0["compactions"],
+            "engine_hbm_gb": eng.sizes.device_bytes / 1e9,
             "roofline": {"bound": "mfma", "kernel": ("az_tower_kernel + az_head_kernel" if args.net == "fused" else "torch Net.forward (MIOpen)")
                                    + ", %d boards/launch" % G,
                          "achieved": net_tflops, "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,

@@ -10,8 +10,9 @@
  * The weights are handed over PRE-PACKED by the host side (alphazero-openspiel_amd/fusednet.py
  * documents and tests the packing): eval-mode BatchNorm folded (bn2 into conv1's weights/bias, bn1
  * kept as a per-channel scale/shift prologue), 3x3 convs laid out as MFMA A-fragments of an implicit
- * GEMM with K = 64 groups x 8 channels (9 taps x 7 channel-groups + 1 group that carries block 1's
- * 1x1 skip conv), fp16 operands, fp32 accumulation, fp32 residual stream.
+ * GEMM with K = 64 groups x 8 channels (9 taps x 7 channel-groups; group 63 is zero padding), fp16
+ * operands, fp32 accumulation, fp32 residual stream; block 1's 1x1 skip conv (network.py:96-97,102-103)
+ * is applied in fp32 straight into the residual stream.
  *
  * Same conventions as az_engine.h: int status returns (0 ok / negative AZ_E_*), no exceptions,
  * az_net_last_error() for text, `stream` = hipStream_t as void*.
@@ -41,6 +42,7 @@ typedef struct az_net_desc {
     const uint16_t *conv_w; /* fp16 bits [2*n_blocks][16 ksteps][4 mtiles][64 lanes][8] */
     const float *conv_epi;  /* [2*n_blocks][3][64]: bias, next-prologue scale, next-prologue shift */
     const float *in_affine; /* [2][8]: block-1 bn1 scale / shift for the input planes */
+    const float *skip_w;    /* [64][4]: block-1 conv3 (1x1) weights, out-channel major, zero padded */
     const uint16_t *fc_w;   /* fp16 bits [n_otiles][H*W*64/32 ksteps][64 lanes][8] */
     const float *fc_b;      /* [n_otiles*16] (bias of fc1, zero padded) */
 } az_net_desc;
