@@ -36,7 +36,10 @@ struct TowerParams {
     int H, W, HW, cells, cin, n_convs, n_boards, bpw;
     int rcells;  // cells per wave region (bpw boards + zero pad), multiple of 16
     int zcell;   // a cell whose whole 3x3 neighbourhood is never written (reads of padding columns land here)
-    int off_act; // LDS byte offset of the activation planes (weight buffers come first)
+    int rs;      // row stride of the cell grid: 8 when W <= 7 ("row-pair tiles"), else W + 1
+    int tpb;     // row-pair mode: column tiles per board = ceil(H / 2); 0 = generic column packing
+    int off_epi; // LDS byte offset of the staged epilogue parameters [n_convs][3][64] floats
+    int off_act; // LDS byte offset of the activation planes
     const _Float16 *conv_w;
     const float *epi;
     const float *skip_w; // [64][4]
@@ -52,21 +55,45 @@ __device__ __forceinline__ int opaque(int v) {
     asm volatile("" : "+v"(v));
     return v;
 }
+// counted LDS wait with a literal operand (n folds to a constant after unrolling)
+__device__ __forceinline__ void wait_lgkm(int n) {
+    switch (n < 15 ? n : 15) {
+    case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt lgkmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); break;
+    }
+}
 // LDS fragment read the compiler does not track (no automatic s_waitcnt): waited for by hand in the k-loop
 __device__ __forceinline__ void lds_read128(half8 &dst, unsigned lds_byte_addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_byte_addr));
 }
 
-// LDS image of one wave: 7 channel-octet planes [rcells][8 fp16]; plane stride is a multiple of 256 B, so the 16
-// lanes of a ds_read_b128 group (8 columns of octet c, 8 columns of octet c+1, consecutive cells) hit 16 different
-// 16-byte bank slots: conflict-free.  cell = board*cells + (y+1)*(W+1) + (x+1); halo cells stay zero.
-template <int NT, int CK>
-__global__ __launch_bounds__(256, 1) void az_tower_kernel(TowerParams p) {
+// LDS image of one wave: 7 channel-octet planes [rcells][8 fp16], plane stride a multiple of 256 B;
+// cell = board*cells + (y+1)*rs + (x+1), halo cells stay zero.  Bank behaviour of the B-fragment ds_read_b128: a lane
+// group is 8 columns of octet c + 8 columns of octet c+1, so it is conflict-free iff the 16 columns of a tile sit in
+// 16 cells that are distinct mod 16.  With a halo column 16 consecutive positions span >= 17 cells (measured: 42 % of
+// LDS cycles were conflicts), so for W <= 7 a column tile is TWO WHOLE ROWS at row stride 8: lane l15 -> row 2t + (l15>>3),
+// x = l15 & 7 = 16 consecutive cells (x = 7 is the shared halo column: a padding lane).  connect_four: 6 tiles per
+// 2 boards either way.  Wider boards keep the generic packing (n = 16*nt + l15 over positions, 2-way conflicts).
+template <int NT, int CK, int OCC>
+__global__ __launch_bounds__(256, OCC) void az_tower_kernel(TowerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int CHUNK_B = CK * 4 * 64 * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l15 = lane & 15;
-    const int W1 = p.W + 1;
     const int plane_b = p.rcells * OCT_B, region_b = N_OCT * plane_b;
     const int board0 = (blockIdx.x * WAVES + wave) * p.bpw; // first global board of this wave
     const int region = p.off_act + wave * region_b;
@@ -76,17 +103,32 @@ __global__ __launch_bounds__(256, 1) void az_tower_kernel(TowerParams p) {
         uint4 z = {0, 0, 0, 0};
         for (int i = lane * 16; i < region_b; i += 64 * 16) *(uint4 *)(lds + region + i) = z;
     }
-    // ---- per-lane tables: column n = 16*nt + l15 of this wave -------------------------------------------
+    // ---- stage the epilogue parameters of every conv in LDS (a global load at each layer end stalls the wave) ----
+    if (p.off_epi >= 0)
+        for (int i = tid * 4; i < p.n_convs * 192; i += 256 * 4) *(f32x4 *)(lds + p.off_epi + i * 4) = *(const f32x4 *)(p.epi + i);
+    // ---- per-lane tables: the NT*16 columns of this wave -----------------------------------------------------
     int pos_addr[NT], grow[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
-        int n = nt * 16 + l15;
-        int b = n / p.HW, pos = n - b * p.HW;
-        bool ok = (b < p.bpw) && (board0 + b < p.n_boards);
-        int y = pos / p.W, x = pos - y * p.W;
-        int cell = b * p.cells + (y + 1) * W1 + (x + 1);
-        pos_addr[nt] = region + (ok ? cell : p.zcell) * OCT_B;
-        grow[nt] = ok ? (board0 + b) * p.HW + pos : -1;
+        int b, y, x;
+        bool ok;
+        if (p.tpb) { // row-pair tile
+            b = nt / p.tpb;
+            y = 2 * (nt - b * p.tpb) + (l15 >> 3);
+            x = l15 & 7;
+            ok = x < p.W && y < p.H;
+        } else {
+            int n = nt * 16 + l15;
+            b = n / p.HW;
+            int pos = n - b * p.HW;
+            y = pos / p.W;
+            x = pos - y * p.W;
+            ok = b < p.bpw;
+        }
+        ok = ok && (board0 + b < p.n_boards);
+        int cell = b * p.cells + (y + 1) * p.rs + (x + 1);
+        pos_addr[nt] = region + ((ok || p.tpb) ? cell : p.zcell) * OCT_B; // row-pair padding lanes read their (finite) neighbours
+        grow[nt] = ok ? (board0 + b) * p.HW + y * p.W + x : -1;
     }
     int koff[AZ_NET_KSTEPS]; // byte offset (tap shift + octet plane) of this lane's k-group in each k-step
 #pragma unroll
@@ -94,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_kernel(TowerParams p) {
         int g = 4 * ks + q;
         int tap = g / 7, c8 = g - tap * 7;
         int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        koff[ks] = g == 63 ? 0 : (dy * W1 + dx) * OCT_B + c8 * plane_b; // group 63: zero weights, any finite data
+        koff[ks] = g == 63 ? 0 : (dy * p.rs + dx) * OCT_B + c8 * plane_b; // group 63: zero weights, any finite data
     }
 
     f32x4 acc[4][NT], xres[4][NT];
@@ -147,57 +189,69 @@ __global__ __launch_bounds__(256, 1) void az_tower_kernel(TowerParams p) {
     issue_chunk(0);
 
     int chunk = 0;
+    constexpr int PARTS = AZ_NET_KSTEPS / CK;
+    static_assert(CK % 2 == 0, "fragment buffer parity relies on an even chunk length");
     for (int conv = 0; conv < p.n_convs; conv++) {
+        half8 a[2][4], b[2][NT]; // fragment double buffer: k-step s+1 is fetched while s is multiplied
 #pragma unroll
-        for (int part = 0; part < AZ_NET_KSTEPS / CK; part++, chunk++) {
-            __syncthreads(); // this chunk's DMA has landed for every wave (vmcnt(0) precedes the barrier); other buffer is free
+        for (int part = 0; part < PARTS; part++, chunk++) {
+            // The weight fragments are read by untracked asm, so hipcc sees no consumer of the LDS-DMA and would NOT wait
+            // for it: wait by hand.  After the barrier every wave's pieces of this chunk have landed and the other
+            // buffer is free for the next chunk's DMA.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             if (chunk + 1 < n_chunks) issue_chunk(chunk + 1);
             // Fragment reads are inline asm so that the compiler neither sinks them next to their first use nor
             // inserts its own lgkmcnt(0) (left alone it waits every 8 MFMAs: 34 % MFMA utilisation).  Order:
             //   wait(all of k-step ksl) ; for each read of k-step ksl+1: {ds_read ; MFMA of ksl} ; remaining MFMAs
             // so a read has most of an MFMA block (16 cycles per MFMA) to land before the next wait.
             const unsigned wbl = lds_base + (chunk & 1) * CHUNK_B + lane * 16;
-            half8 a[2][4], b[2][NT];
+            // Read order inside a k-step: A0..A3, B0, B1, ... (read index: A_mt = mt, B_nt = 4 + nt).  LDS returns in
+            // order, so before the MFMAs of column tile nt it is enough to wait until at most (reads issued after
+            // B_nt) are outstanding: counted s_waitcnt instead of lgkmcnt(0).
 #pragma unroll
             for (int mt = 0; mt < 4; mt++) lds_read128(a[0][mt], wbl + mt * 1024);
-            {
-                int ko = opaque(koff[part * CK]); // keep pos_addr + koff out of LICM's hands (it would hoist NT*16 sums)
+            if (part == 0) { // later chunks of a conv had their B fragments fetched before the barrier
+                int ko = opaque(koff[0]); // keep pos_addr + koff out of LICM's hands (it would hoist NT*16 sums)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) lds_read128(b[0][nt], lds_base + pos_addr[nt] + ko);
             }
 #pragma unroll
             for (int ksl = 0; ksl < CK; ksl++) {
                 const int cur = ksl & 1, nxt = cur ^ 1;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                int issued = 0; // MFMAs of this k-step issued so far, in (nt, mt) order
-                if (ksl + 1 < CK) {
-                    const int ko = opaque(koff[part * CK + ksl + 1]);
+                const bool more_here = ksl + 1 < CK;                   // next k-step is in this chunk: A and B
+                const bool more_next = !more_here && part + 1 < PARTS; // next k-step is in the next chunk: B only
+                const int n_next = more_here ? NT + 4 : (more_next ? NT : 0); // reads to issue during this k-step
+                const bool first_of_chunk = ksl == 0;
+                const int ko = (more_here || more_next) ? opaque(koff[part * CK + ksl + 1]) : 0;
+                int issued_next = 0;
 #pragma unroll
-                    for (int i = 0; i < NT + 4; i++) {
-                        if (i < 4) lds_read128(a[nxt][i], wbl + ((ksl + 1) * 4 + i) * 1024);
-                        else lds_read128(b[nxt][i - 4], lds_base + pos_addr[i - 4] + ko);
-                        {
-                            const int nt = issued >> 2, mt = issued & 3;
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
-                            issued++;
-                        }
+                for (int j = 0; j < 4 * NT; j++) {
+                    const int nt = j >> 2, mt = j & 3;
+                    if (mt == 0) {
+                        // reads of THIS k-step still allowed in flight: those after B_nt; plus all reads of the next one
+                        // issued so far.  (First k-step of a later chunk: its B came before the barrier, its A after ->
+                        // everything of this k-step must be in.)
+                        int after = (first_of_chunk && part > 0) ? 0 : NT - 1 - nt;
+                        wait_lgkm(after + issued_next);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                }
-#pragma unroll
-                for (int j = 0; j < 4 * NT; j++)
-                    if (j >= issued) {
-                        const int nt = j >> 2, mt = j & 3;
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
+                    if (issued_next < n_next) { // one read of the next k-step per MFMA, in the same order
+                        const int r = more_here ? issued_next : issued_next + 4; // B-only prefetch skips the A slots
+                        if (r < 4) lds_read128(a[nxt][r], wbl + ((ksl + 1) * 4 + r) * 1024);
+                        else lds_read128(b[nxt][r - 4], lds_base + pos_addr[r - 4] + ko);
+                        issued_next++;
                     }
-                __builtin_amdgcn_sched_barrier(0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // nothing of mine in flight when the epilogue touches LDS
         // ---- epilogue of this conv (the wave's own boards only: no barrier needed) ------------------------
         // The accumulators were initialised with this conv's bias, so: conv1: u = lrelu(acc); conv2: x += acc,
         // a = lrelu(scale*x + shift).  LeakyReLU runs on the packed fp16 values (v_pk_mul_f16 + v_pk_max_f16).
-        const float *ep = p.epi + (size_t)conv * 3 * 64;
+        const float *ep = p.off_epi >= 0 ? (const float *)(lds + p.off_epi) + conv * 192 : p.epi + conv * 192;
         const bool is_conv2 = conv & 1, last = conv == p.n_convs - 1;
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) {
@@ -308,7 +362,7 @@ struct az_net {
     float *epi = nullptr, *fc_b = nullptr, *skip_w = nullptr;
     float in_affine[16];
     int max_boards = 0;
-    int bpw_max = 0, cells = 0, lds_head = 0, n_ot = 0;
+    int bpw_max = 0, lds_head = 0, n_ot = 0;
 };
 static std::string g_net_err;
 
@@ -338,18 +392,40 @@ extern "C" int az_net_destroy(az_net *n) {
 
 // geometry of one launch for a given boards-per-wave
 struct TowerGeom {
-    int bpw, nt, ck, rcells, zcell, lds;
+    int bpw, nt, ck, occ, rcells, zcell, rs, tpb, cells, off_epi, off_act, lds;
 };
-static TowerGeom tower_geom(int bpw, int H, int W) {
+static TowerGeom tower_geom(int bpw, int H, int W, int n_convs) {
     TowerGeom g;
-    int cells = (H + 2) * (W + 1) + 1, zpad = 2 * (W + 2) + 1;
     g.bpw = bpw;
-    g.nt = (bpw * H * W + 15) / 16;
-    g.rcells = (bpw * cells + zpad + 15) & ~15;
-    g.zcell = bpw * cells + (W + 2);
-    int act = WAVES * N_OCT * g.rcells * OCT_B;
-    g.ck = (act + 2 * 8 * 4096 <= 160 * 1024 && g.nt <= 7) ? 8 : 4; // 32 KiB weight chunks when LDS and registers allow
-    g.lds = act + 2 * g.ck * 4096;
+    if (W <= 7) { // row-pair tiles at row stride 8 (conflict-free B reads)
+        g.rs = 8;
+        g.tpb = (H + 1) / 2;
+        g.nt = bpw * g.tpb;
+    } else {
+        g.rs = W + 1;
+        g.tpb = 0;
+        g.nt = (bpw * H * W + 15) / 16;
+    }
+    g.cells = (H + 2) * g.rs + 1;
+    int zpad = 2 * (g.rs + 1) + 1;
+    g.rcells = (bpw * g.cells + zpad + 15) & ~15;
+    g.zcell = bpw * g.cells + (g.rs + 1);
+    int act = WAVES * N_OCT * g.rcells * OCT_B, epi = n_convs * 192 * 4;
+    g.occ = 1;
+    if (g.nt <= 3 && act + 2 * 4 * 4096 <= 80 * 1024) {
+        // small tiles: <= 256 registers and <= 80 KiB LDS -> TWO workgroups per CU (2 waves per SIMD), so one wave's
+        // epilogue / waits overlap the other's MFMAs.  Epilogue parameters then stay in global memory (L2).
+        g.occ = 2;
+        g.ck = 4;
+        g.off_epi = -1;
+        g.off_act = 2 * g.ck * 4096;
+        g.lds = g.off_act + act;
+        return g;
+    }
+    g.ck = (act + epi + 2 * 8 * 4096 <= 160 * 1024 && g.nt <= 7) ? 8 : 4; // 32 KiB weight chunks when LDS and registers allow
+    g.off_epi = 2 * g.ck * 4096;
+    g.off_act = g.off_epi + epi;
+    g.lds = g.off_act + act;
     return g;
 }
 
@@ -374,11 +450,10 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     n->d = d;
     memcpy(n->in_affine, d.in_affine, sizeof n->in_affine);
     const int HW = d.rows * d.cols;
-    n->cells = (d.rows + 2) * (d.cols + 1) + 1;
     // boards per wave: up to 8 column tiles (128 columns; 9 would spill registers) within the 160 KiB LDS
     int best = 0;
     for (int bpw = 1; bpw <= 8; bpw++) {
-        TowerGeom g = tower_geom(bpw, d.rows, d.cols);
+        TowerGeom g = tower_geom(bpw, d.rows, d.cols, 2 * d.n_blocks);
         if (g.nt > 8 || g.lds > 160 * 1024) break;
         best = bpw;
     }
@@ -437,18 +512,21 @@ extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
     return AZ_OK;
 }
 
-template <int NT, int CK> static hipError_t launch_tower(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
+template <int NT, int CK, int OCC> static hipError_t launch_tower(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
     static bool attr_set[16] = {false};
     if (!attr_set[n->d.device & 15]) {
-        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT, CK, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (s != hipSuccess) return s;
         attr_set[n->d.device & 15] = true;
     }
-    hipLaunchKernelGGL((az_tower_kernel<NT, CK>), dim3(grid), dim3(256), lds, st, tp);
+    hipLaunchKernelGGL((az_tower_kernel<NT, CK, OCC>), dim3(grid), dim3(256), lds, st, tp);
     return hipGetLastError();
 }
 template <int NT> static hipError_t launch_tower_ck(const az_net *n, const TowerParams &tp, int grid, const TowerGeom &g, hipStream_t st) {
-    return g.ck == 8 ? launch_tower<NT, 8>(n, tp, grid, g.lds, st) : launch_tower<NT, 4>(n, tp, grid, g.lds, st);
+    if constexpr (NT <= 3) {
+        if (g.occ == 2) return launch_tower<NT, 4, 2>(n, tp, grid, g.lds, st);
+    }
+    return g.ck == 8 ? launch_tower<NT, 8, 1>(n, tp, grid, g.lds, st) : launch_tower<NT, 4, 1>(n, tp, grid, g.lds, st);
 }
 
 extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float *values, int32_t n_boards, void *stream) {
@@ -460,13 +538,14 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     hipStream_t st = (hipStream_t)stream;
     // boards per wave: one workgroup (4 waves) per CU is resident, a launch runs in ceil(WGs / 256) rounds and a
     // round costs ~ (column tiles + fixed part): pick the bpw that minimises rounds x tiles for THIS batch size.
-    TowerGeom g = tower_geom(1, n->d.rows, n->d.cols);
+    TowerGeom g = tower_geom(1, n->d.rows, n->d.cols, 2 * n->d.n_blocks);
     {
         long best_cost = -1;
         for (int bpw = 1; bpw <= n->bpw_max; bpw++) {
-            TowerGeom c = tower_geom(bpw, n->d.rows, n->d.cols);
+            TowerGeom c = tower_geom(bpw, n->d.rows, n->d.cols, 2 * n->d.n_blocks);
             long wgs = (n_boards + WAVES * bpw - 1) / (WAVES * bpw);
-            long cost = ((wgs + 255) / 256) * (2 * (c.nt < 3 ? 3 : c.nt) + 1);
+            long cost = ((wgs + 256 * c.occ - 1) / (256 * c.occ)) * (2 * (c.nt < 3 ? 3 : c.nt) + 1) * (c.occ == 2 ? 3 : 2);
+            // (two co-resident workgroups share the MFMA pipes: a round of them costs ~1.5x a single-occupancy round)
             if (best_cost < 0 || cost <= best_cost) {
                 best_cost = cost;
                 g = c;
@@ -477,14 +556,17 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     tp.H = n->d.rows;
     tp.W = n->d.cols;
     tp.HW = tp.H * tp.W;
-    tp.cells = n->cells;
+    tp.cells = g.cells;
+    tp.rs = g.rs;
+    tp.tpb = g.tpb;
+    tp.off_epi = g.off_epi;
     tp.cin = n->d.in_planes;
     tp.n_convs = 2 * n->d.n_blocks;
     tp.n_boards = n_boards;
     tp.bpw = g.bpw;
     tp.rcells = g.rcells;
     tp.zcell = g.zcell;
-    tp.off_act = 2 * g.ck * 4096;
+    tp.off_act = g.off_act;
     tp.conv_w = n->conv_w;
     tp.epi = n->epi;
     tp.skip_w = n->skip_w;

@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse several ranks on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,7 +119,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        dist.init_process_group(args.backend)
+    local_rank = local_rank % max(1, torch.cuda.device_count())  # rehearsal: several ranks may share one GPU (gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -206,7 +209,8 @@ def main():
     sims = p1["sims"] - p0["sims"]
     evals = p1["evals"] - p0["evals"]
     moves = p1["moves"] - p0["moves"]
-    tot = torch.tensor([dt, float(games), float(sims), float(evals), float(moves)], dtype=torch.float64, device=device)
+    tot = torch.tensor([dt, float(games), float(sims), float(evals), float(moves)], dtype=torch.float64,
+                       device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
