@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libaz_engine.so")
+LIB_PATH = os.environ.get("AZ_ENGINE_LIB") or os.path.join(HERE, "libaz_engine.so")  # env override: profiling builds
 
 GAME_CONNECT_FOUR, GAME_BREAKTHROUGH = 0, 1
 BACKUPS = {"on-policy": 0, "soft-Z": 1, "A0C": 2, "off-policy": 3}

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/az_engine.h"
@@ -28,9 +29,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Timing-only ablation switches (make ABL="-DAZ_ABL_..."): each removes one ingredient of the tower's inner
+// structure so its cost can be read off the clock.  Outputs are wrong by construction; never shipped.
+//   AZ_ABL_NOEPI   no epilogue arithmetic / LDS writes        AZ_ABL_NOB    no B-fragment (activation) LDS reads
+//   AZ_ABL_NOA     no A-fragment (weight) LDS reads           AZ_ABL_NODMA  no weight DMA and no chunk barrier
 #define OCT_B 16 // one cell of one channel-octet plane: 8 fp16
 #define N_OCT 7  // 56 channels
-#define WAVES 4
 
 struct TowerParams {
     int H, W, HW, cells, cin, n_convs, n_boards, bpw;
@@ -38,10 +42,10 @@ struct TowerParams {
     int zcell;   // a cell whose whole 3x3 neighbourhood is never written (reads of padding columns land here)
     int rs;      // row stride of the cell grid: 8 when W <= 7 ("row-pair tiles"), else W + 1
     int tpb;     // row-pair mode: column tiles per board = ceil(H / 2); 0 = generic column packing
-    int off_epi; // LDS byte offset of the staged epilogue parameters [n_convs][3][64] floats
+    int off_epi; // LDS byte offset of the epilogue-parameter ring: 2 slots x [4][64] floats (scale, shift, next bias)
     int off_act; // LDS byte offset of the activation planes
     const _Float16 *conv_w;
-    const float *epi;
+    const float *epi;    // [n_convs][4][64]: bias, next-prologue scale, shift, bias of the NEXT conv
     const float *skip_w; // [64][4]
     float in_scale[8], in_shift[8];
     const float *obs;
@@ -80,6 +84,16 @@ __device__ __forceinline__ void wait_lgkm(int n) {
 __device__ __forceinline__ void lds_read128(half8 &dst, unsigned lds_byte_addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_byte_addr));
 }
+#ifdef AZ_ABL_NOA
+#define READ_A(dst, addr) asm volatile("" : "=v"(dst) : "v"(addr))
+#else
+#define READ_A(dst, addr) lds_read128(dst, addr)
+#endif
+#ifdef AZ_ABL_NOB
+#define READ_B(dst, addr) asm volatile("" : "=v"(dst) : "v"(addr))
+#else
+#define READ_B(dst, addr) lds_read128(dst, addr)
+#endif
 
 // LDS image of one wave: 7 channel-octet planes [rcells][8 fp16], plane stride a multiple of 256 B;
 // cell = board*cells + (y+1)*rs + (x+1), halo cells stay zero.  Bank behaviour of the B-fragment ds_read_b128: a lane
@@ -88,8 +102,8 @@ __device__ __forceinline__ void lds_read128(half8 &dst, unsigned lds_byte_addr) 
 // LDS cycles were conflicts), so for W <= 7 a column tile is TWO WHOLE ROWS at row stride 8: lane l15 -> row 2t + (l15>>3),
 // x = l15 & 7 = 16 consecutive cells (x = 7 is the shared halo column: a padding lane).  connect_four: 6 tiles per
 // 2 boards either way.  Wider boards keep the generic packing (n = 16*nt + l15 over positions, 2-way conflicts).
-template <int NT, int CK, int OCC>
-__global__ __launch_bounds__(256, OCC) void az_tower_kernel(TowerParams p) {
+template <int NT, int CK, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int CHUNK_B = CK * 4 * 64 * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,14 +112,12 @@ __global__ __launch_bounds__(256, OCC) void az_tower_kernel(TowerParams p) {
     const int board0 = (blockIdx.x * WAVES + wave) * p.bpw; // first global board of this wave
     const int region = p.off_act + wave * region_b;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const int trash = p.off_epi + 2048 + tid * 8; // per-thread dump slot for masked-out epilogue stores
 
     { // zero the wave's private planes (halo + padding must read as 0)
         uint4 z = {0, 0, 0, 0};
         for (int i = lane * 16; i < region_b; i += 64 * 16) *(uint4 *)(lds + region + i) = z;
     }
-    // ---- stage the epilogue parameters of every conv in LDS (a global load at each layer end stalls the wave) ----
-    if (p.off_epi >= 0)
-        for (int i = tid * 4; i < p.n_convs * 192; i += 256 * 4) *(f32x4 *)(lds + p.off_epi + i * 4) = *(const f32x4 *)(p.epi + i);
     // ---- per-lane tables: the NT*16 columns of this wave -----------------------------------------------------
     int pos_addr[NT], grow[NT];
 #pragma unroll
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(256, OCC) void az_tower_kernel(TowerParams p) {
         const unsigned char *src = (const unsigned char *)p.conv_w + (size_t)c * CHUNK_B;
         unsigned char *dst = lds + (c & 1) * CHUNK_B;
 #pragma unroll
-        for (int i = 0; i < CHUNK_B / (256 * 16); i++) {
+        for (int i = 0; i < CHUNK_B / (WAVES * 64 * 16); i++) {
             int piece = i * WAVES + wave; // one KiB per wave-instruction, lane-linear
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
@@ -198,9 +210,15 @@ __global__ __launch_bounds__(256, OCC) void az_tower_kernel(TowerParams p) {
             // The weight fragments are read by untracked asm, so hipcc sees no consumer of the LDS-DMA and would NOT wait
             // for it: wait by hand.  After the barrier every wave's pieces of this chunk have landed and the other
             // buffer is free for the next chunk's DMA.
+#ifndef AZ_ABL_NODMA
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (chunk + 1 < n_chunks) issue_chunk(chunk + 1);
+            if (part == 0 && wave == 0) // this conv's epilogue parameters ride the same DMA path into a 2-slot ring; they
+                                        // land before the next chunk barrier, i.e. long before the epilogue reads them
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + (size_t)conv * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(lds + p.off_epi + (conv & 1) * 1024), 16, 0, 0);
+#endif
             // Fragment reads are inline asm so that the compiler neither sinks them next to their first use nor
             // inserts its own lgkmcnt(0) (left alone it waits every 8 MFMAs: 34 % MFMA utilisation).  Order:
             //   wait(all of k-step ksl) ; for each read of k-step ksl+1: {ds_read ; MFMA of ksl} ; remaining MFMAs
@@ -210,11 +228,11 @@ __global__ __launch_bounds__(256, OCC) void az_tower_kernel(TowerParams p) {
             // order, so before the MFMAs of column tile nt it is enough to wait until at most (reads issued after
             // B_nt) are outstanding: counted s_waitcnt instead of lgkmcnt(0).
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) lds_read128(a[0][mt], wbl + mt * 1024);
+            for (int mt = 0; mt < 4; mt++) READ_A(a[0][mt], wbl + mt * 1024);
             if (part == 0) { // later chunks of a conv had their B fragments fetched before the barrier
                 int ko = opaque(koff[0]); // keep pos_addr + koff out of LICM's hands (it would hoist NT*16 sums)
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++) lds_read128(b[0][nt], lds_base + pos_addr[nt] + ko);
+                for (int nt = 0; nt < NT; nt++) READ_B(b[0][nt], lds_base + pos_addr[nt] + ko);
             }
 #pragma unroll
             for (int ksl = 0; ksl < CK; ksl++) {
@@ -238,8 +256,8 @@ __global__ __launch_bounds__(256, OCC) void az_tower_kernel(TowerParams p) {
                     }
                     if (issued_next < n_next) { // one read of the next k-step per MFMA, in the same order
                         const int r = more_here ? issued_next : issued_next + 4; // B-only prefetch skips the A slots
-                        if (r < 4) lds_read128(a[nxt][r], wbl + ((ksl + 1) * 4 + r) * 1024);
-                        else lds_read128(b[nxt][r - 4], lds_base + pos_addr[r - 4] + ko);
+                        if (r < 4) READ_A(a[nxt][r], wbl + ((ksl + 1) * 4 + r) * 1024);
+                        else READ_B(b[nxt][r - 4], lds_base + pos_addr[r - 4] + ko);
                         issued_next++;
                     }
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
@@ -251,35 +269,53 @@ __global__ __launch_bounds__(256, OCC) void az_tower_kernel(TowerParams p) {
         // ---- epilogue of this conv (the wave's own boards only: no barrier needed) ------------------------
         // The accumulators were initialised with this conv's bias, so: conv1: u = lrelu(acc); conv2: x += acc,
         // a = lrelu(scale*x + shift).  LeakyReLU runs on the packed fp16 values (v_pk_mul_f16 + v_pk_max_f16).
-        const float *ep = p.off_epi >= 0 ? (const float *)(lds + p.off_epi) + conv * 192 : p.epi + conv * 192;
-        const bool is_conv2 = conv & 1, last = conv == p.n_convs - 1;
+        // Three straight-line variants picked ONCE per conv (left to the compiler the uniform conditions were
+        // re-tested, with branches and exec masking, for every tile); stores are unconditional: padding lanes and
+        // the non-existent 8th octet go to a per-lane trash slot.
+        const float *ep = (const float *)(lds + p.off_epi + (conv & 1) * 1024);
+        auto epilogue = [&](auto kind) {
+            constexpr int KIND = decltype(kind)::value; // 0: conv1, 1: conv2 (not last), 2: last conv
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-            const int co0 = 16 * mt + 4 * q;
-            const int woff = (2 * mt + (q >> 1)) * plane_b + (q & 1) * 8; // octet plane + half of the octet
-            const bool wr = (2 * mt + (q >> 1)) < N_OCT;
-            f32x4 sc = *(const f32x4 *)(ep + 64 + co0), sh = *(const f32x4 *)(ep + 128 + co0);
-            f32x4 next_bias = last ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4 *)(ep + 192 + co0);
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                f32x4 v = acc[mt][nt];
-                acc[mt][nt] = next_bias;
-                half4 o;
-                if (!is_conv2) {
-                    o = lrelu_h4(__builtin_convertvector(v, half4));
-                } else {
-                    f32x4 xv = xres[mt][nt] + v;
-                    xres[mt][nt] = xv;
-                    if (last) {
-                        o = __builtin_convertvector(xv, half4);
-                        if (grow[nt] >= 0) *(half4 *)(p.xout + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = o;
-                        continue;
-                    }
-                    o = lrelu_h4(__builtin_convertvector(sc * xv + sh, half4));
+            for (int mt = 0; mt < 4; mt++) {
+                const int co0 = 16 * mt + 4 * q;
+                const bool wr = (2 * mt + (q >> 1)) < N_OCT;
+                const int woff = (2 * mt + (q >> 1)) * plane_b + (q & 1) * 8; // octet plane + half of the octet
+                f32x4 sc, sh;
+                if (KIND == 1) {
+                    sc = *(const f32x4 *)(ep + 64 + co0);
+                    sh = *(const f32x4 *)(ep + 128 + co0);
                 }
-                if (wr && grow[nt] >= 0) *(half4 *)(lds + pos_addr[nt] + woff) = o;
+                f32x4 next_bias = *(const f32x4 *)(ep + 192 + co0);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    f32x4 v = acc[mt][nt];
+                    acc[mt][nt] = next_bias;
+#ifdef AZ_ABL_NOEPI
+                    asm volatile("" ::"v"(v));
+                    if (KIND == 2 && grow[nt] >= 0) *(half4 *)(p.xout + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = __builtin_convertvector(v, half4);
+                    continue;
+#endif
+                    half4 o;
+                    if (KIND == 0) {
+                        o = lrelu_h4(__builtin_convertvector(v, half4));
+                    } else {
+                        f32x4 xv = xres[mt][nt] + v;
+                        xres[mt][nt] = xv;
+                        if (KIND == 2) {
+                            o = __builtin_convertvector(xv, half4);
+                            if (grow[nt] >= 0) *(half4 *)(p.xout + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = o;
+                            continue;
+                        }
+                        o = lrelu_h4(__builtin_convertvector(sc * xv + sh, half4));
+                    }
+                    const int wa = (wr && grow[nt] >= 0) ? pos_addr[nt] + woff : trash;
+                    *(half4 *)(lds + wa) = o;
+                }
             }
-        }
+        };
+        if (!(conv & 1)) epilogue(std::integral_constant<int, 0>{});
+        else if (conv != p.n_convs - 1) epilogue(std::integral_constant<int, 1>{});
+        else epilogue(std::integral_constant<int, 2>{});
     }
 }
 
@@ -392,9 +428,9 @@ extern "C" int az_net_destroy(az_net *n) {
 
 // geometry of one launch for a given boards-per-wave
 struct TowerGeom {
-    int bpw, nt, ck, occ, rcells, zcell, rs, tpb, cells, off_epi, off_act, lds;
+    int bpw, nt, ck, waves, rcells, zcell, rs, tpb, cells, off_epi, off_act, lds;
 };
-static TowerGeom tower_geom(int bpw, int H, int W, int n_convs) {
+static TowerGeom tower_geom(int bpw, int waves, int H, int W) {
     TowerGeom g;
     g.bpw = bpw;
     if (W <= 7) { // row-pair tiles at row stride 8 (conflict-free B reads)
@@ -410,21 +446,16 @@ static TowerGeom tower_geom(int bpw, int H, int W, int n_convs) {
     int zpad = 2 * (g.rs + 1) + 1;
     g.rcells = (bpw * g.cells + zpad + 15) & ~15;
     g.zcell = bpw * g.cells + (g.rs + 1);
-    int act = WAVES * N_OCT * g.rcells * OCT_B, epi = n_convs * 192 * 4;
-    g.occ = 1;
-    if (g.nt <= 3 && act + 2 * 4 * 4096 <= 80 * 1024) {
-        // small tiles: <= 256 registers and <= 80 KiB LDS -> TWO workgroups per CU (2 waves per SIMD), so one wave's
-        // epilogue / waits overlap the other's MFMAs.  Epilogue parameters then stay in global memory (L2).
-        g.occ = 2;
-        g.ck = 4;
-        g.off_epi = -1;
-        g.off_act = 2 * g.ck * 4096;
-        g.lds = g.off_act + act;
-        return g;
-    }
-    g.ck = (act + epi + 2 * 8 * 4096 <= 160 * 1024 && g.nt <= 7) ? 8 : 4; // 32 KiB weight chunks when LDS and registers allow
+    int wave_act = N_OCT * g.rcells * OCT_B;
+    // waves = 8 (512 threads): small tiles only (<= 256 registers/wave), 2 waves per SIMD, so one wave's epilogue / waits
+    // overlap another's MFMAs, and the eight share ONE weight stream (two co-resident 4-wave workgroups each pull their
+    // own: at 1 board per wave that is ~25 TB/s of L2 reads chip-wide).
+    g.waves = waves;
+    int act = g.waves * wave_act;
+    // 32 KiB weight chunks (half the barriers) when LDS allows; not with 8 waves: the longer unrolled body spills there
+    g.ck = (act + 6144 + 2 * 8 * 4096 <= 160 * 1024 && g.waves == 4) ? 8 : 4; // 32 KiB chunks when LDS/registers allow
     g.off_epi = 2 * g.ck * 4096;
-    g.off_act = g.off_epi + epi;
+    g.off_act = g.off_epi + 2048 + 8 * 64 * 8; // epilogue ring (2 KiB) + trash slots (8 B per thread, up to 512 threads)
     g.lds = g.off_act + act;
     return g;
 }
@@ -450,11 +481,12 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     n->d = d;
     memcpy(n->in_affine, d.in_affine, sizeof n->in_affine);
     const int HW = d.rows * d.cols;
-    // boards per wave: up to 8 column tiles (128 columns; 9 would spill registers) within the 160 KiB LDS
+    // boards per wave: at most 4 column tiles per wave (larger tiles spill registers under the hand-scheduled k-loop
+    // and measured slower than more, smaller waves) within the 160 KiB LDS
     int best = 0;
     for (int bpw = 1; bpw <= 8; bpw++) {
-        TowerGeom g = tower_geom(bpw, d.rows, d.cols, 2 * d.n_blocks);
-        if (g.nt > 8 || g.lds > 160 * 1024) break;
+        TowerGeom g = tower_geom(bpw, 4, d.rows, d.cols);
+        if (g.nt > 4 || g.lds > 160 * 1024) break;
         best = bpw;
     }
     if (!best) {
@@ -482,7 +514,15 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
         }
     };
     up((void **)&n->conv_w, d.conv_w, cw);
-    up((void **)&n->epi, d.conv_epi, ep);
+    {   // [conv][3][64] (ABI) -> [conv][4][64] with the NEXT conv's bias in row 3 (what the kernel's ring slot holds)
+        int nc = 2 * d.n_blocks;
+        std::vector<float> e4((size_t)nc * 256, 0.f);
+        for (int c = 0; c < nc; c++) {
+            memcpy(&e4[(size_t)c * 256], d.conv_epi + (size_t)c * 192, 192 * sizeof(float));
+            if (c + 1 < nc) memcpy(&e4[(size_t)c * 256 + 192], d.conv_epi + (size_t)(c + 1) * 192, 64 * sizeof(float));
+        }
+        up((void **)&n->epi, e4.data(), e4.size() * sizeof(float));
+    }
     up((void **)&n->fc_w, d.fc_w, fw);
     up((void **)&n->fc_b, d.fc_b, fb);
     up((void **)&n->skip_w, d.skip_w, 64 * 4 * sizeof(float));
@@ -512,21 +552,21 @@ extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
     return AZ_OK;
 }
 
-template <int NT, int CK, int OCC> static hipError_t launch_tower(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
+template <int NT, int CK, int WAVES> static hipError_t launch_tower(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
     static bool attr_set[16] = {false};
     if (!attr_set[n->d.device & 15]) {
-        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT, CK, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT, CK, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (s != hipSuccess) return s;
         attr_set[n->d.device & 15] = true;
     }
-    hipLaunchKernelGGL((az_tower_kernel<NT, CK, OCC>), dim3(grid), dim3(256), lds, st, tp);
+    hipLaunchKernelGGL((az_tower_kernel<NT, CK, WAVES>), dim3(grid), dim3(WAVES * 64), lds, st, tp);
     return hipGetLastError();
 }
 template <int NT> static hipError_t launch_tower_ck(const az_net *n, const TowerParams &tp, int grid, const TowerGeom &g, hipStream_t st) {
     if constexpr (NT <= 3) {
-        if (g.occ == 2) return launch_tower<NT, 4, 2>(n, tp, grid, g.lds, st);
+        if (g.waves == 8) return launch_tower<NT, 4, 8>(n, tp, grid, g.lds, st);
     }
-    return g.ck == 8 ? launch_tower<NT, 8, 1>(n, tp, grid, g.lds, st) : launch_tower<NT, 4, 1>(n, tp, grid, g.lds, st);
+    return g.ck == 8 ? launch_tower<NT, 8, 4>(n, tp, grid, g.lds, st) : launch_tower<NT, 4, 4>(n, tp, grid, g.lds, st);
 }
 
 extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float *values, int32_t n_boards, void *stream) {
@@ -538,19 +578,25 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     hipStream_t st = (hipStream_t)stream;
     // boards per wave: one workgroup (4 waves) per CU is resident, a launch runs in ceil(WGs / 256) rounds and a
     // round costs ~ (column tiles + fixed part): pick the bpw that minimises rounds x tiles for THIS batch size.
-    TowerGeom g = tower_geom(1, n->d.rows, n->d.cols, 2 * n->d.n_blocks);
+    // Work partition for THIS batch size.  Candidates: boards per wave x {4, 8} waves per workgroup.  A launch runs in
+    // ceil(WGs / resident WGs) rounds; a round costs ~ (2*tiles + 1), x1.5 when two waves share each SIMD.
+    TowerGeom g = tower_geom(1, 4, n->d.rows, n->d.cols);
     {
-        long best_cost = -1;
-        for (int bpw = 1; bpw <= n->bpw_max; bpw++) {
-            TowerGeom c = tower_geom(bpw, n->d.rows, n->d.cols, 2 * n->d.n_blocks);
-            long wgs = (n_boards + WAVES * bpw - 1) / (WAVES * bpw);
-            long cost = ((wgs + 256 * c.occ - 1) / (256 * c.occ)) * (2 * (c.nt < 3 ? 3 : c.nt) + 1) * (c.occ == 2 ? 3 : 2);
-            // (two co-resident workgroups share the MFMA pipes: a round of them costs ~1.5x a single-occupancy round)
-            if (best_cost < 0 || cost <= best_cost) {
-                best_cost = cost;
-                g = c;
+        double best_cost = -1;
+        for (int bpw = 1; bpw <= n->bpw_max; bpw++)
+            for (int waves = 4; waves <= 8; waves += 4) {
+                TowerGeom c = tower_geom(bpw, waves, n->d.rows, n->d.cols);
+                if (c.lds > 160 * 1024 || (waves == 8 && c.nt > 3)) continue; // 8 waves need <= 256 registers each
+                long wgs = (n_boards + waves * bpw - 1) / (waves * bpw);
+                int per_cu = 1; // every variant's registers/LDS admit one workgroup per CU
+                long rounds = (wgs + 256 * per_cu - 1) / (256 * per_cu);
+                bool two_per_simd = waves == 8 || (per_cu == 2 && wgs > 256);
+                double cost = rounds * (2.0 * (c.nt < 3 ? 3 : c.nt) + 1.0) * (two_per_simd ? 1.5 : 1.0);
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    g = c;
+                }
             }
-        }
     }
     TowerParams tp;
     tp.H = n->d.rows;
@@ -574,15 +620,11 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     memcpy(tp.in_shift, n->in_affine + 8, 32);
     tp.obs = obs;
     tp.xout = n->xout;
-    int per_wg = WAVES * g.bpw, grid = (n_boards + per_wg - 1) / per_wg;
+    int per_wg = g.waves * g.bpw, grid = (n_boards + per_wg - 1) / per_wg;
     hipError_t s;
     switch (g.nt < 3 ? 3 : g.nt) {
     case 3: s = launch_tower_ck<3>(n, tp, grid, g, st); break;
-    case 4: s = launch_tower_ck<4>(n, tp, grid, g, st); break;
-    case 5: s = launch_tower_ck<5>(n, tp, grid, g, st); break;
-    case 6: s = launch_tower_ck<6>(n, tp, grid, g, st); break;
-    case 7: s = launch_tower_ck<7>(n, tp, grid, g, st); break;
-    default: s = launch_tower_ck<8>(n, tp, grid, g, st); break;
+    default: s = launch_tower_ck<4>(n, tp, grid, g, st); break;
     }
     if (s != hipSuccess) {
         n->err = std::string("tower launch: ") + hipGetErrorString(s);
