@@ -6,13 +6,9 @@ Replaces the pickled `pool.map_async(...).get()` gather of reference examplegene
 The payload is the engine's compact record (bitboards + root child visits), not the dense
 float64 boards: ~0.1 kB/ply for connect_four instead of ~1.6 kB.
 """
-import io
-
 import numpy as np
 import torch
 import torch.distributed as dist
-
-_KEYS = ("game_len", "game_ret0", "states", "move", "n_children", "child_action", "child_visits", "value")
 
 
 def world_size():
@@ -23,21 +19,47 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+_SPEC = (("game_len", np.int32, 0), ("game_ret0", np.float32, 0), ("states", np.uint64, 2), ("move", np.uint16, 1),
+         ("n_children", np.uint8, 1), ("child_action", np.uint16, 3), ("child_visits", np.uint32, 3),
+         ("value", np.float64, 1))   # name, dtype, kind: 0 = [n], 1 = [n, plies], 2 = [n, plies, 2], 3 = [n, plies, maxc]
+_MAGIC = 0x415A5231  # "AZR1"
+
+
+def _shape(kind, n, plies, maxc):
+    return {0: (n,), 1: (n, plies), 2: (n, plies, 2), 3: (n, plies, maxc)}[kind]
+
+
 def pack_export(ex):
-    """export dict -> (uint8 numpy payload, meta) trimmed to the plies actually played."""
+    """export dict -> flat uint8 numpy payload: 5 x int64 header + the arrays back to back (8-byte aligned), trimmed
+    to the plies actually played.  One memcpy per array; no container format (a 20k-game export packs in ~20 ms)."""
     n = len(ex["game_len"])
     p0 = int(ex["start_ply"])
-    used = p0 + (int(ex["game_len"].max()) if n else 0)
-    trimmed = {k: (ex[k][:, :used] if ex[k].ndim >= 2 else ex[k]) for k in _KEYS}
-    buf = io.BytesIO()
-    np.savez(buf, start_ply=np.int64(p0), **trimmed)
-    return np.frombuffer(buf.getvalue(), dtype=np.uint8).copy()
+    plies = p0 + (int(ex["game_len"].max()) if n else 0)
+    maxc = ex["child_action"].shape[2]
+    parts = [np.array([_MAGIC, n, plies, maxc, p0], dtype=np.int64).view(np.uint8)]
+    for name, dtype, kind in _SPEC:
+        a = ex[name]
+        if kind:
+            a = a[:, :plies]
+        b = np.ascontiguousarray(a, dtype=dtype).reshape(-1).view(np.uint8)
+        parts.append(b)
+        if b.size % 8:
+            parts.append(np.zeros(8 - b.size % 8, dtype=np.uint8))
+    return np.concatenate(parts)
 
 
 def unpack_export(payload):
-    with np.load(io.BytesIO(payload.tobytes())) as z:
-        ex = {k: z[k] for k in _KEYS}
-        ex["start_ply"] = int(z["start_ply"])
+    """Inverse of pack_export; the arrays are views into the payload (no copies)."""
+    payload = np.ascontiguousarray(payload, dtype=np.uint8)
+    magic, n, plies, maxc, p0 = (int(x) for x in payload[:40].view(np.int64))
+    if magic != _MAGIC:
+        raise ValueError("not an export payload")
+    ex, off = {"start_ply": p0}, 40
+    for name, dtype, kind in _SPEC:
+        shape = _shape(kind, n, plies, maxc)
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ex[name] = payload[off:off + nbytes].view(dtype).reshape(shape)
+        off += (nbytes + 7) & ~7
     return ex
 
 
