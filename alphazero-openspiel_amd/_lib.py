@@ -59,7 +59,16 @@ class AzNetDesc(C.Structure):
                 ("fc_w", C.POINTER(C.c_uint16)), ("fc_b", C.POINTER(C.c_float))]
 
 
-# every symbol include/az_engine.h and include/az_net.h declare: (name, restype, argtypes)
+class AzReplayConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("game", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("device", C.c_int32), ("reserved", C.c_int32), ("max_games", C.c_int64), ("max_examples", C.c_int64)]
+
+
+class AzReplayStats(C.Structure):
+    _fields_ = [("n_games", C.c_int64), ("n_examples", C.c_int64), ("n_unique", C.c_int64), ("games_dropped", C.c_int64)]
+
+
+# every symbol include/az_engine.h, include/az_net.h and include/az_replay.h declare: (name, restype, argtypes)
 _vp = C.c_void_p
 PROTOTYPES = [
     ("az_engine_create", C.c_int, [C.POINTER(AzConfig), C.POINTER(_vp)]),
@@ -85,6 +94,19 @@ PROTOTYPES = [
     ("az_net_forward", C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),
     ("az_net_reserve", C.c_int, [_vp, C.c_int32]),
     ("az_net_read_tower", C.c_int, [_vp, C.POINTER(C.c_float), C.c_int32]),
+    ("az_replay_create", C.c_int, [C.POINTER(AzReplayConfig), C.POINTER(_vp)]),
+    ("az_replay_destroy", C.c_int, [_vp]),
+    ("az_replay_last_error", C.c_char_p, [_vp]),
+    ("az_replay_set_capacity", C.c_int, [_vp, C.c_int64]),
+    ("az_replay_append_engine", C.c_int, [_vp, _vp, _vp]),
+    ("az_replay_append_host", C.c_int, [_vp, C.POINTER(AzExampleView), C.c_int32, _vp]),
+    ("az_replay_dedupe", C.c_int, [_vp, _vp]),
+    ("az_replay_sample", C.c_int, [_vp, _vp, C.c_int32, C.c_uint64, _vp, _vp, _vp, _vp]),
+    ("az_replay_stats_get", C.c_int, [_vp, C.POINTER(AzReplayStats)]),
+    ("az_replay_read_unique", C.c_int64, [_vp, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_int32)]),
+    ("az_replay_read_example", C.c_int, [_vp, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]
 
 _lib = None

@@ -1,0 +1,81 @@
+// az_engine_internal.h — definitions shared by az_engine.hip and az_replay.hip (NOT part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/az_engine.h"
+#include "az_games.h"
+
+#define NONE32 0xFFFFFFFFu
+
+enum { PH_IDLE = 0, PH_RUN = 1, PH_MOVE = 2, PH_WAIT_ROOT = 3, PH_WAIT_LEAF = 4, PH_SEARCH_DONE = 5, PH_NEED_ROOT = 6 };
+enum { ST_MOVES = 0, ST_SIMS, ST_EVALS, ST_TERM, ST_DEPTH, ST_CHILDREN, ST_NODES, ST_COMPACT, ST_N };
+
+struct PwPlan { // numpy pairwise-sum recursion for a length-A vector, flattened (see np_sum_sparse)
+    int n_blocks;
+    int lo[16], len[16];
+    int n_ops;
+    int ops[32]; // >=0: push block i, -1: add top two
+};
+
+struct Params {
+    // geometry / config
+    AzGeom geom;
+    int game, A, maxc, max_plies, obs_elems, pstride;
+    int G, S, use_dirichlet, keep_tree, backup, rng_mode, max_sims_per_tick, manual_moves;
+    uint32_t cap, need_per_move;
+    double c_puct, one_minus_ratio, alpha, inv_temp;
+    uint64_t seed;
+    long long n_games, max_games;
+    AzState start;
+    PwPlan pw;
+    // node pools
+    uint32_t *N, *C0, *META;
+    double *Q, *P;
+    // per slot
+    int *phase, *gid, *ply, *sims, *which, *depth, *leaf_ply;
+    uint32_t *root, *alloc, *leaf_node, *path;
+    uint64_t *bb0, *bb1, *leaf_bb0, *leaf_bb1;
+    unsigned long long *stats; // [G][ST_N]
+    // global counters
+    unsigned long long *next_game, *games_done;
+    unsigned int *faults;
+    // injected randomness
+    const double *etas, *us;
+    double *eta_buf; // [G][maxc] Dirichlet draw staged with the root request (Philox mode)
+    // records
+    int *rec_len;
+    float *rec_ret0;
+    uint64_t *rec_states;
+    uint16_t *rec_move, *rec_child_action;
+    uint8_t *rec_nchild;
+    uint32_t *rec_child_visits;
+    double *rec_value;
+};
+
+
+struct az_engine {
+    az_config cfg;
+    Params p;
+    az_sizes sizes;
+    std::string err;
+    std::vector<void *> dev_allocs;
+    bool reset_done = false;
+    int64_t n_games = 0;
+    double *d_etas = nullptr, *d_us = nullptr;
+    int *d_actions = nullptr;
+    int64_t ticks = 0;
+    int64_t inj_games = 0;
+    // host mirrors for export
+    std::vector<int32_t> h_len;
+    std::vector<float> h_ret0;
+    std::vector<uint64_t> h_states;
+    std::vector<uint16_t> h_move, h_child_action;
+    std::vector<uint8_t> h_nchild;
+    std::vector<uint32_t> h_child_visits;
+    std::vector<double> h_value;
+};
+

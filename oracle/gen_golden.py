@@ -17,6 +17,8 @@ oracle/fakepolicy.py as policy_fn):
   net_forward_*.npz   network.Net.forward of the two shipped checkpoints on
                       fixed boards (fp32, CPU) + the checkpoint tensors re-packed
                       as .npz (data fixture; lets the GPU box run the same net)
+  replay.json         Trainer.remove_duplicates over two generations + FIFO trim, the net_step batch gather and one
+                      net_step update (train.py:95-130,156-201,226-236)
   rules_*.json        random playouts of oracle/pygames.py (NOT reference output:
                       OpenSpiel is absent; rules are "parity unpinned")
 
@@ -290,6 +292,81 @@ def gen_rules():
     return out
 
 
+def gen_replay(ref):
+    """Trainer.remove_duplicates (train.py:156-201) over two generations of reference self-play games with the FIFO
+    trim in between (train.py:226-236), the net_step batch gather (train.py:107-120) and one net_step update
+    (train.py:95-130) with the shipped connect_four checkpoint."""
+    import types
+
+    import torch
+
+    Trainer = ref.train.Trainer
+    AZB = ref.alphazerobot.AlphaZeroBot
+    orig_step = AZB.step
+    game_name, S, salt = "connect_four", 12, 41
+    game = pygames.load_game(game_name)
+    A = game.num_distinct_actions()
+    shape = game.information_state_normalized_vector_shape()
+    pf = fakepolicy.make_policy_fn(ref.network.state_to_board, shape, A, salt)
+    games, records = [], []
+    for k in range(10):
+        per_move = []
+
+        def step(self, state, _pm=per_move):
+            policy, action = orig_step(self, state)
+            _pm.append({"actions": root_stats(self.mcts.root)["actions"], "cN": root_stats(self.mcts.root)["cN"],
+                        "action": int(action)})
+            return policy, action
+
+        np.random.seed(500 + k)
+        AZB.step = step
+        try:
+            ex = ref.game_utils.play_game_self(pf, game_name, n_playouts=S, temperature=1.0, dirichlet_ratio=0.25,
+                                               c_puct=2.5, backup="on-policy")
+        finally:
+            AZB.step = orig_step
+        games.append(ex)
+        records.append({"moves": per_move, "z0": float(ex[0][3])})
+
+    def snapshot(flat):
+        return [{"key": it[0], "pi": [float(x) for x in it[2]], "z": float(it[3])} for it in flat]
+
+    buffer = list(games[:6])
+    out1 = Trainer.remove_duplicates([s for g in buffer for s in g])
+    snap1 = snapshot(out1)
+    buffer += games[6:]
+    n_games_buffer = 8
+    while len(buffer) > n_games_buffer:
+        del buffer[0]
+    flat2 = [s for g in buffer for s in g]
+    out2 = Trainer.remove_duplicates(flat2)
+    snap2 = snapshot(out2)
+    np.random.seed(5)
+    ids = np.random.randint(len(out2), size=16)
+    batch = {"ids": [int(i) for i in ids],
+             "x": [board_bits(out2[i][1]) for i in ids],
+             "pi": [[float(np.float32(v)) for v in out2[i][2]] for i in ids],
+             "z": [float(np.float32(out2[i][3])) for i in ids]}
+    # one net_step with the shipped checkpoint (CPU, fp32), the same 16 samples
+    sd = torch.load(os.path.join(ref_harness.REFERENCE_DIR, "models", "example_model_connect_four.pth"),
+                    map_location="cpu", weights_only=True)
+    net = ref.network.Net(shape, A)
+    net.load_state_dict(sd)
+    net.train()
+    torch.set_num_threads(1)
+    fake = types.SimpleNamespace(current_net=net, batch_size=16, device=torch.device("cpu"),
+                                 criterion_value=torch.nn.MSELoss(), it=0,
+                                 optimizer=torch.optim.Adam(net.parameters(), lr=0.001, weight_decay=0.0001))
+    np.random.seed(5)
+    loss_p, loss_v = Trainer.net_step(fake, out2)
+    after = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    step = {"loss_p": float(loss_p), "loss_v": float(loss_v),
+            "fc1_bias_after": [float(x) for x in after["fc1.bias"]],
+            "conv_w_sum_after": float(np.abs(after["resblock3.conv1.weight"]).sum())}
+    return {"game": game_name, "n_playouts": S, "salt": salt, "records": records, "first_generation": 6,
+            "n_games_buffer": n_games_buffer, "dedupe1": snap1, "dedupe2": snap2, "batch": batch, "net_step": step}
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_harness.load_reference()
@@ -305,6 +382,7 @@ def main():
     for tag, blob in gen_rules().items():
         dump("rules_%s.json" % tag, blob)
     print("net_forward:", gen_net_forward(ref))
+    dump("replay.json", gen_replay(ref))
 
 
 if __name__ == "__main__":

@@ -64,7 +64,8 @@ _cached = None
 
 def load_reference():
     """Import the reference's hot-path modules unmodified; returns a namespace
-    with .mcts .alphazerobot .game_utils .network attributes."""
+    with .mcts .alphazerobot .game_utils .network .examplegenerator .train attributes (train.Trainer is only ever used
+    through its static / unbound methods: instantiating it would open log files)."""
     global _cached
     if _cached is not None:
         return _cached
@@ -73,7 +74,7 @@ def load_reference():
     sys.dont_write_bytecode = True  # never write __pycache__ into the read-only tree
     _install_stub_pyspiel()
     saved = {}
-    names = ("mcts", "network", "alphazerobot", "game_utils")
+    names = ("mcts", "network", "alphazerobot", "game_utils", "examplegenerator", "train")
     for n in names:  # do not clobber same-named modules of the caller
         if n in sys.modules:
             saved[n] = sys.modules.pop(n)

@@ -137,7 +137,7 @@ def test_examples_have_the_reference_record_format(name):
 # ------------------------------------------------------------------------------------------ C ABI
 def _declared_symbols():
     names = set()
-    for hdr in ("az_engine.h", "az_net.h"):
+    for hdr in ("az_engine.h", "az_net.h", "az_replay.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(az_[a-z_0-9]+)\s*\(", text))
@@ -155,16 +155,18 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_structs_match_the_c_layout(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "az_engine.h"\n#include "az_net.h"\n'
-                   'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(az_config), sizeof(az_sizes), '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "az_engine.h"\n#include "az_net.h"\n#include "az_replay.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(az_config), sizeof(az_sizes), '
                    'sizeof(az_progress), sizeof(az_example_view), sizeof(az_slot_info), sizeof(az_net_desc), '
-                   'offsetof(az_config, seed), offsetof(az_progress, error_flags));return 0;}\n')
+                   'offsetof(az_config, seed), offsetof(az_progress, error_flags), sizeof(az_replay_config), '
+                   'sizeof(az_replay_stats));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(_lib.AzConfig), ctypes.sizeof(_lib.AzSizes), ctypes.sizeof(_lib.AzProgress),
             ctypes.sizeof(_lib.AzExampleView), ctypes.sizeof(_lib.AzSlotInfo), ctypes.sizeof(_lib.AzNetDesc),
-            _lib.AzConfig.seed.offset, _lib.AzProgress.error_flags.offset]
+            _lib.AzConfig.seed.offset, _lib.AzProgress.error_flags.offset, ctypes.sizeof(_lib.AzReplayConfig),
+            ctypes.sizeof(_lib.AzReplayStats)]
     assert got == want
 
 

@@ -1,0 +1,178 @@
+"""Replay store: Trainer.remove_duplicates / FIFO / batch gather / net_step.
+
+CPU: the Python restatement (oracle/pyreplay.py) and the façade's net_step against fixtures produced by the
+reference's own Trainer methods.  GPU: the HIP replay store through the C ABI — bit-exact (float64 sums in buffer
+order) against the same fixtures and, for engine-produced generations, against the restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from alphazero_openspiel_amd import games
+from alphazero_openspiel_amd.network import load_npz_checkpoint
+from oracle import pyreplay
+
+
+def _fixture():
+    return load_golden("replay.json")
+
+
+def _games_as_export(fx, idxs):
+    """fixture records -> arrays in the engine's export layout (what az_replay_append_host takes)."""
+    game = games.load_game(fx["game"])
+    mp, mc = game.max_game_length(), game.max_children()
+    n = len(idxs)
+    ex = {"game_len": np.zeros(n, np.int32), "game_ret0": np.zeros(n, np.float32),
+          "states": np.zeros((n, mp, 2), np.uint64), "move": np.zeros((n, mp), np.uint16),
+          "n_children": np.zeros((n, mp), np.uint8), "child_action": np.zeros((n, mp, mc), np.uint16),
+          "child_visits": np.zeros((n, mp, mc), np.uint32), "value": np.zeros((n, mp)), "start_ply": 0}
+    for j, g in enumerate(idxs):
+        rec = fx["records"][g]
+        s = game.new_initial_state()
+        z = rec["z0"]
+        for i, m in enumerate(rec["moves"]):
+            ex["states"][j, i] = s.bb
+            ex["n_children"][j, i] = len(m["actions"])
+            ex["child_action"][j, i, :len(m["actions"])] = m["actions"]
+            ex["child_visits"][j, i, :len(m["cN"])] = m["cN"]
+            ex["move"][j, i] = m["action"]
+            ex["value"][j, i] = z
+            z = -z
+            s.apply_action(m["action"])
+        ex["game_len"][j] = len(rec["moves"])
+        ex["game_ret0"][j] = rec["z0"]
+    return game, ex
+
+
+def _flat_examples(fx, idxs):
+    from alphazero_openspiel_amd.engine import examples_from_export
+    game, ex = _games_as_export(fx, idxs)
+    return examples_from_export(game, ex)
+
+
+def test_restatement_matches_reference_trainer():
+    fx = _fixture()
+    buffer = _flat_examples(fx, range(fx["first_generation"]))
+    out1 = pyreplay.remove_duplicates([s for g in buffer for s in g])
+    assert [(o[0], o[2], o[3]) for o in out1] == [(w["key"], w["pi"], w["z"]) for w in fx["dedupe1"]]
+    buffer = pyreplay.fifo_append(buffer, _flat_examples(fx, range(fx["first_generation"], len(fx["records"]))),
+                                  fx["n_games_buffer"])
+    out2 = pyreplay.remove_duplicates([s for g in buffer for s in g])
+    assert [(o[0], o[2], o[3]) for o in out2] == [(w["key"], w["pi"], w["z"]) for w in fx["dedupe2"]]
+
+
+def _batch_tensors(fx, device):
+    b = fx["batch"]
+    x = torch.tensor([[float(c) for c in row] for row in b["x"]], dtype=torch.float32).reshape(-1, 4, 6, 7).to(device)
+    return x, torch.tensor(b["pi"], dtype=torch.float32, device=device), torch.tensor(b["z"], dtype=torch.float32, device=device)
+
+
+def _net_step_case(device, tol):
+    from alphazero_openspiel_amd import replay
+    fx = _fixture()
+    net = load_npz_checkpoint(os.path.join(GOLDEN, "checkpoint_connect_four.npz"), [3, 6, 7], 7).to(device)
+    net.train()
+    opt = replay.make_optimizer(net)
+    x, pi, z = _batch_tensors(fx, device)
+    loss_p, loss_v = replay.net_step(net, opt, x, pi, z)
+    want = fx["net_step"]
+    loss_p, loss_v = loss_p.detach(), loss_v.detach()
+    assert abs(float(loss_p) - want["loss_p"]) <= tol * abs(want["loss_p"])
+    assert abs(float(loss_v) - want["loss_v"]) <= tol * abs(want["loss_v"])
+    after = net.state_dict()
+    assert np.allclose(after["fc1.bias"].cpu().numpy(), want["fc1_bias_after"], rtol=0, atol=20 * tol)
+    assert abs(float(after["resblock3.conv1.weight"].abs().sum()) - want["conv_w_sum_after"]) <= 50 * tol * want["conv_w_sum_after"]
+
+
+def test_net_step_matches_reference_trainer_cpu():
+    torch.set_num_threads(1)
+    _net_step_case(torch.device("cpu"), 2e-6)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _unique_as_tuples(rep, game, hist_of_index):
+    u = rep.read_unique()
+    return [(hist_of_index[int(i)], u["pi"][k].tolist(), float(u["z"][k])) for k, i in enumerate(u["buffer_index"])]
+
+
+def _history_index(fx, idxs):
+    """logical buffer index -> history string, for games idxs in buffer order"""
+    out = []
+    for g in idxs:
+        moves = [m["action"] for m in fx["records"][g]["moves"]]
+        for i in range(len(moves)):
+            out.append(", ".join(str(a) for a in moves[:i]))
+    return out
+
+
+@pytest.mark.gpu
+def test_device_dedupe_fifo_and_gather_match_reference_trainer():
+    from alphazero_openspiel_amd import replay
+    fx = _fixture()
+    n1 = fx["first_generation"]
+    game, ex1 = _games_as_export(fx, range(n1))
+    rep = replay.DeviceReplay(fx["game"], max_games=16, device=0)
+    rep.append_export(ex1)
+    assert rep.dedupe() == len(fx["dedupe1"])
+    got = _unique_as_tuples(rep, game, _history_index(fx, range(n1)))
+    assert got == [(w["key"], w["pi"], w["z"]) for w in fx["dedupe1"]]
+    # second generation: FIFO trim to n_games_buffer, dedupe again over the (written-back) buffer
+    rep.set_capacity(fx["n_games_buffer"])
+    _, ex2 = _games_as_export(fx, range(n1, len(fx["records"])))
+    rep.append_export(ex2)
+    st = rep.stats()
+    kept = list(range(len(fx["records"]) - fx["n_games_buffer"], len(fx["records"])))
+    assert st["n_games"] == fx["n_games_buffer"] and st["games_dropped"] == len(fx["records"]) - fx["n_games_buffer"]
+    assert rep.dedupe() == len(fx["dedupe2"])
+    got = _unique_as_tuples(rep, game, _history_index(fx, kept))
+    assert got == [(w["key"], w["pi"], w["z"]) for w in fx["dedupe2"]]
+    # the net_step gather with the reference's np.random.randint draw
+    b = fx["batch"]
+    x, pi, z = rep.sample(len(b["ids"]), indices=b["ids"])
+    assert ["".join(str(int(c)) for c in row) for row in x.cpu().numpy().reshape(len(b["ids"]), -1)] == b["x"]
+    assert pi.cpu().numpy().tolist() == b["pi"]
+    assert z.cpu().numpy().tolist() == b["z"]
+    # device-drawn indices stay in range and differ call to call
+    xa, _, _ = rep.sample(64, seed=3)
+    xb, _, _ = rep.sample(64, seed=3)
+    assert xa.shape == (64, 4, 6, 7) and not torch.equal(xa, xb)
+    rep.close()
+
+
+@pytest.mark.gpu
+def test_net_step_matches_reference_trainer_gpu():
+    _net_step_case(torch.device("cuda:0"), 2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,backup", [("connect_four", "on-policy"), ("breakthrough(rows=6,columns=6)", "soft-Z")])
+def test_engine_to_replay_device_path_matches_host_path(name, backup):
+    """engine records -> az_replay_append_engine (device to device) -> dedupe  ==  engine.export -> reference-format
+    examples -> the restatement of remove_duplicates, for two generations."""
+    from alphazero_openspiel_amd import engine as E, replay
+    from alphazero_openspiel_amd.network import Net
+    game = games.load_game(name)
+    torch.manual_seed(1)
+    net = Net(game.information_state_normalized_vector_shape(), game.num_distinct_actions(), n_blocks=2, n_filters=16)
+    ev = E.DeviceEvaluator(net, "cuda:0")
+    rep = replay.DeviceReplay(name, max_games=40, device=0)
+    rep.set_capacity(40)
+    buffer = []
+    for gen in range(2):
+        eng = E.SelfPlayEngine(name, 16, n_playouts=8, max_games=24, backup=backup, seed=10 + gen)
+        E.run_selfplay(eng, ev, 24)
+        rep.append_engine(eng)
+        host_games = E.examples_from_export(game, eng.export())
+        eng.close()
+        buffer = pyreplay.fifo_append(buffer, host_games, 40)
+        want = pyreplay.remove_duplicates([s for g in buffer for s in g])
+        assert rep.dedupe() == len(want)
+        u = rep.read_unique()
+        assert [p.tolist() for p in u["pi"]] == [w[2] for w in want]
+        assert u["z"].tolist() == [w[3] for w in want]
+        boards = games.boards_from_bitboards(game, u["bitboards"], u["ply"])
+        assert all((boards[k] == want[k][1]).all() for k in range(len(want)))
+    assert rep.stats()["n_games"] == 40 and rep.stats()["games_dropped"] == 8
+    rep.close()
