@@ -17,6 +17,7 @@ Weights are stored in "fragment-linear" order: for k-step ks, output tile mt, la
     co = 16*mt + (l & 15),  group = 4*ks + (l >> 4)
 which is the v_mfma_f32_16x16x32_f16 A-operand map, so a wave reads one contiguous KiB per fragment.
 """
+import copy
 import ctypes as C
 
 import numpy as np
@@ -57,7 +58,8 @@ def _pack_conv(w3x3):
 
 def pack_net(net):
     """Net (alphazero_openspiel_amd.network.Net or the reference's Net) -> dict of packed numpy arrays."""
-    net = net.eval()
+    if net.training:
+        raise ValueError("pack_net folds BatchNorm running statistics: call net.eval() first (or pass a copy)")
     F_ = net.n_filts
     blocks = [getattr(net, "resblock%d" % (i + 1)) for i in range(getattr(net, "n_blocks", 5))]
     H, W, A = net.height, net.width, net.num_distinct_actions
@@ -194,7 +196,7 @@ class FusedNet:
             raise RuntimeError("FusedNet needs a HIP device; there is no CPU path")
         self.device_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", self.device_index)
-        self.packed = pack_net(net.cpu() if next(net.parameters()).is_cuda else net)
+        self.packed = pack_net(copy.deepcopy(net).cpu().eval())  # never move or switch the caller's module
         p = self.packed
         d = _lib.AzNetDesc()
         d.struct_size = C.sizeof(_lib.AzNetDesc)

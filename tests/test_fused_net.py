@@ -109,5 +109,5 @@ def test_fused_net_rejects_bad_arguments():
     with pytest.raises(RuntimeError):
         fn.forward(torch.zeros(4, 4, 6, 7, device="cuda", dtype=torch.float16))
     with pytest.raises(ValueError):
-        fusednet.pack_net(Net([3, 6, 7], 7, n_blocks=2, n_filters=64))  # > 56 filters
+        fusednet.pack_net(Net([3, 6, 7], 7, n_blocks=2, n_filters=64).eval())  # > 56 filters
     fn.close()
