@@ -81,6 +81,7 @@ PROTOTYPES = [
     ("az_engine_advance", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("az_engine_update_root", C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32, _vp]),
     ("az_engine_progress", C.c_int, [_vp, C.POINTER(AzProgress), _vp]),
+    ("az_engine_poll", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_uint32), _vp]),
     ("az_engine_export", C.c_int, [_vp, C.POINTER(AzExampleView), _vp]),
     ("az_engine_read_root", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double),

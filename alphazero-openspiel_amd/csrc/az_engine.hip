@@ -1163,6 +1163,23 @@ extern "C" int az_engine_progress(az_engine *e, az_progress *out, void *stream) 
     return AZ_OK;
 }
 
+extern "C" int az_engine_poll(az_engine *e, int64_t *games_done, uint32_t *error_flags, void *stream) {
+    if (!e) return AZ_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long done = 0;
+    unsigned int faults = 0;
+    HIPCHK(e, hipMemcpyAsync(&done, e->p.games_done, sizeof done, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(&faults, e->p.faults, sizeof faults, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    if (games_done) *games_done = (int64_t)done;
+    if (error_flags) *error_flags = faults;
+    if (faults) {
+        e->err = "device fault flags set (see az_engine_progress)";
+        return AZ_E_DEVICE;
+    }
+    return AZ_OK;
+}
+
 extern "C" int az_engine_export(az_engine *e, az_example_view *out, void *stream) {
     if (!e || !out) return AZ_E_INVALID;
     HIPCHK(e, hipSetDevice(e->cfg.device));

@@ -115,12 +115,13 @@ class SelfPlayEngine:
         self._check(self.lib.az_engine_set_start_prefix(self._h, arr, len(actions)))
         self.start_history = [int(a) for a in actions]
 
-    def set_injected_rng(self, etas, us):
-        """etas: per game, per ply, the Dirichlet draw (ragged lists ok); us: per game, per ply uniforms."""
+    def set_injected_rng(self, etas, us, absolute_ply=False):
+        """etas: per game, per ply, the Dirichlet draw (ragged lists ok); us: per game, per ply uniforms.  Lists are
+        indexed by plies played since the start position unless absolute_ply (then by the state's ply number)."""
         n = len(us)
         e = np.zeros((n, self.max_plies, self.max_children), dtype=np.float64)
         u = np.zeros((n, self.max_plies), dtype=np.float64)
-        off = len(self.start_history)
+        off = 0 if absolute_ply else len(self.start_history)
         for g in range(n):
             for i, row in enumerate(etas[g] if etas is not None else []):
                 e[g, off + i, :len(row)] = row
@@ -152,6 +153,15 @@ class SelfPlayEngine:
         if check:
             self._check(rc)
         return {name: getattr(p, name) for name, _ in _lib.AzProgress._fields_ if name != "reserved"}
+
+    def games_done(self):
+        """Cheap poll (two words) for the tick loop; raises on device faults like progress()."""
+        done, flags = C.c_int64(), C.c_uint32()
+        rc = self.lib.az_engine_poll(self._h, C.byref(done), C.byref(flags), self._stream())
+        if rc < 0:
+            self.progress()  # raises with the decoded fault names
+            self._check(rc)
+        return done.value
 
     def read_root(self, slot):
         mc = self.max_children
@@ -322,10 +332,10 @@ def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_tick
             ticks += 1
             if on_tick is not None:
                 on_tick(engine, ticks)
-        prog = engine.progress()
-        if prog["games_done"] >= n_games:
+        if engine.games_done() >= n_games:
             break
         if max_ticks is not None and ticks >= max_ticks:
-            raise EngineError("self-play did not finish within %d ticks: %r" % (max_ticks, prog))
+            raise EngineError("self-play did not finish within %d ticks: %r" % (max_ticks, engine.progress()))
+    prog = engine.progress()
     prog["ticks"] = ticks
     return prog

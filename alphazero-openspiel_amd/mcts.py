@@ -133,11 +133,9 @@ class MCTS:
         if self.use_dirichlet:  # the draw of mcts.py:187, from numpy's global stream
             n_legal = len(state.legal_actions(state.current_player()))
             eta = np.random.dirichlet(0.3 * np.ones(n_legal))
-            e.start_history = []
-            e.set_injected_rng([[[0.0]] * ply + [list(eta)]], [[0.0] * (ply + 1)])
+            e.set_injected_rng([[[0.0]] * ply + [list(eta)]], [[0.0] * (ply + 1)], absolute_ply=True)
         else:
-            e.start_history = []
-            e.set_injected_rng(None, [[0.0] * (ply + 1)])
+            e.set_injected_rng(None, [[0.0] * (ply + 1)], absolute_ply=True)
         for _ in range(4 * self.n_playouts + 16):
             e.advance(pri, val, obs)
             info = e.read_slot(0)

@@ -178,9 +178,8 @@ def main():
             for _ in range(args.check_every):
                 tick()
             ticks += args.check_every
-            p = eng.progress()
-            if p["games_done"] >= n_done:
-                return p, ticks
+            if eng.games_done() >= n_done:
+                return eng.progress(), ticks
 
     # ---- warm-up: W steps (W*G games completed) -------------------------------------------------
     if Wm > 0:

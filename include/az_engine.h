@@ -179,6 +179,10 @@ int az_engine_update_root(az_engine *e, const int32_t *actions, int32_t keep_sub
 /* Counters; synchronises `stream`. */
 int az_engine_progress(az_engine *e, az_progress *out, void *stream);
 
+/* Cheap completion poll for the tick loop: number of finished games and the device fault flags (two words, one
+ * small copy); synchronises `stream`.  Returns AZ_E_DEVICE if a fault flag is set. */
+int az_engine_poll(az_engine *e, int64_t *games_done, uint32_t *error_flags, void *stream);
+
 /* Copy finished games to host memory owned by the engine; synchronises `stream`. */
 int az_engine_export(az_engine *e, az_example_view *out, void *stream);
 

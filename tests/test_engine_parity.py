@@ -48,8 +48,7 @@ def test_search_trace_matches_reference(idx):
     eng.set_start_prefix(case["prefix"])
     eng.reset(1)
     ply = len(case["prefix"])
-    eng.start_history = []
-    eng.set_injected_rng([[[0.0]] * ply + [case["eta"] or [0.0]]], [[0.0] * (ply + 1)])
+    eng.set_injected_rng([[[0.0]] * ply + [case["eta"] or [0.0]]], [[0.0] * (ply + 1)], absolute_ply=True)
     obs, pri, val = eng.alloc_io()
     ev = E.HostPolicyEvaluator(eng, _board_fn(eng.A, case["salt"]))
     seen = set()
