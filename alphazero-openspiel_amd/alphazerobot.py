@@ -1,10 +1,15 @@
-"""`AlphaZeroBot` with the reference's interface (alphazerobot.py:21-93) on the GPU search.
+"""`AlphaZeroBot` with the reference's interface (alphazerobot.py:21-93), search on the GPU.
 
-step(state) = re-root the device tree from state.history(), run the search in HIP kernels
-(mcts.MCTS façade), then the reference's host arithmetic on the visit counts — mask + renormalise,
-temperature, `np.random.choice` from numpy's global stream — so seeded runs draw what the reference
-draws.  The bulk self-play path does NOT go through this class: ExampleGenerator keeps thousands of
-games resident on the device and samples moves there (Philox).
+One `step(state)`:
+  1. bring the device tree's root to `state` (re-root by the last move(s) when `keep_search_tree`, else a
+     fresh tree)                                                          reference alphazerobot.py:54-68
+  2. run the S sequential playouts in the HIP kernels (mcts.MCTS façade)   reference alphazerobot.py:71
+  3. host arithmetic on the root visit fractions, with numpy exactly as the reference does it — illegal-move
+     mask + renormalisation, temperature, then `np.random.choice` / argmax — so a seeded run draws the same
+     random numbers as the reference                                      reference alphazerobot.py:72-93
+
+The bulk self-play path does NOT go through this class: ExampleGenerator keeps thousands of games resident on
+the device and samples moves there (Philox).
 """
 import numpy as np
 
@@ -12,59 +17,59 @@ from .mcts import MCTS
 
 
 def remove_illegal_actions(action_probabilities, legal_actions):
-    """Zero illegal entries, renormalise; all-illegal mass -> uniform over legal (alphazerobot.py:7-18)."""
-    keep = np.zeros(action_probabilities.shape, dtype=bool)
-    keep[legal_actions] = True
-    action_probabilities[~keep] = 0.0
-    total = np.sum(action_probabilities)
-    if total > 1e-6:
-        return action_probabilities / total
-    uniform = np.zeros(len(action_probabilities))
-    uniform[legal_actions] = 1. / len(legal_actions)
-    return uniform
+    """alphazerobot.py:7-18 — drop the mass on illegal actions and renormalise; when (almost) no mass is left
+    on legal ones, fall back to uniform over them."""
+    legal_mask = np.zeros(action_probabilities.shape, dtype=bool)
+    legal_mask[legal_actions] = True
+    action_probabilities[~legal_mask] = 0.0
+    mass = np.sum(action_probabilities)
+    if mass > 1e-6:
+        return action_probabilities / mass
+    fallback = np.zeros(len(action_probabilities))
+    fallback[legal_actions] = 1. / len(legal_actions)
+    return fallback
+
+
+def _tempered(pi, temperature):
+    powered = pi ** (1. / temperature)
+    return powered / sum(powered)
 
 
 class AlphaZeroBot:
     def __init__(self, game, player, policy_fn, self_play=False, keep_search_tree=True, **kwargs):
         self.num_distinct_actions = game.num_distinct_actions()
-        self.player = player
-        self.policy_fn = policy_fn
-        self.kwargs = kwargs
+        self.player, self.policy_fn, self.kwargs = player, policy_fn, kwargs
+        self.self_play, self.keep_search_tree = self_play, keep_search_tree
         self.use_probabilistic_actions = bool(self_play) or bool(kwargs.get("use_probabilistic_actions"))
         self.use_random_actions = bool(kwargs.get("use_random_actions", False))
         self.num_probabilistic_actions = int(kwargs.get("num_probabilistic_actions", 1000))
         self.temperature = float(kwargs.get("temperature", 1.0))
-        self.self_play = self_play
-        self.keep_search_tree = keep_search_tree
         self.mcts = MCTS(policy_fn, self.num_distinct_actions, **kwargs)
 
-    def step(self, state):
-        """-> (policy [(action, prob) for legal actions], action)"""
-        if self.keep_search_tree:
-            hist = state.history()
-            if self.self_play:
-                if hist:
-                    self.mcts.update_root(hist[-1])
-            elif len(hist) >= 2:
-                self.mcts.update_root(hist[-2])
-                self.mcts.update_root(hist[-1])
-        else:
-            old = self.mcts
+    def _advance_tree(self, history):
+        if not self.keep_search_tree:  # a new search tree every step (the engine slot is reused, its tree is not)
+            previous = self.mcts
             self.mcts = MCTS(self.policy_fn, self.num_distinct_actions, **self.kwargs)
-            self.mcts._engine, self.mcts._io, self.mcts._evaluator = old._engine, old._io, old._evaluator
-            if old._engine is not None:
-                self.mcts._game = old._game
-            self.mcts._history = None  # forces a fresh tree at the next search
+            self.mcts.adopt_engine(previous)
+            return
+        recent = history[-1:] if self.self_play else (history[-2:] if len(history) >= 2 else [])
+        for move in recent:
+            self.mcts.update_root(move)
 
-        visits = np.array(self.mcts.search(state))
+    def _pick(self, tempered, legal, n_played):
+        early = n_played < self.num_probabilistic_actions
+        if self.use_random_actions and early:
+            return np.random.choice(legal)
+        if self.use_probabilistic_actions and early:
+            return np.random.choice(len(tempered), p=tempered)
+        return np.argmax(tempered)
+
+    def step(self, state):
+        """-> (policy [(action, prob) for legal actions] — un-tempered, action)"""
+        history = state.history()
+        self._advance_tree(history)
+        fractions = np.array(self.mcts.search(state))
         legal = state.legal_actions(state.current_player())
-        pi = remove_illegal_actions(visits, legal)
-        tempered = pi ** (1. / self.temperature) / sum(pi ** (1. / self.temperature))
-        n_played = len(state.history())
-        if self.use_random_actions and n_played < self.num_probabilistic_actions:
-            action = np.random.choice(legal)
-        elif self.use_probabilistic_actions and n_played < self.num_probabilistic_actions:
-            action = np.random.choice(len(tempered), p=tempered)
-        else:
-            action = np.argmax(tempered)
+        pi = remove_illegal_actions(fractions, legal)
+        action = self._pick(_tempered(pi, self.temperature), legal, len(history))
         return [(a, pi[a]) for a in legal], action

@@ -123,6 +123,15 @@ class MCTS:
         pri.copy_(torch.tensor(np.asarray(p, dtype=np.float32)).reshape(1, -1))
         val.fill_(float(v))
 
+    def adopt_engine(self, other):
+        """Take over another façade's engine slot (AlphaZeroBot with keep_search_tree=False builds a new MCTS per
+        step: the device resources are reused, the tree is not)."""
+        self._engine, self._io, self._evaluator = other._engine, other._io, other._evaluator
+        if other._engine is not None:
+            self._game = other._game
+        self._history = None  # forces a fresh tree at the next search
+        other._engine = None
+
     # ------------------------------------------------------------------ reference interface
     def search(self, state):
         self._ensure_engine(state)
