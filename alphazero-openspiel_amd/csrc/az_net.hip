@@ -390,12 +390,74 @@ __global__ __launch_bounds__(256) void az_head_kernel(HeadParams p) {
     }
 }
 
+// Large action spaces (breakthrough: 433 / 769 outputs = 28 / 49 output tiles): the single-kernel head above keeps only
+// 4 waves per CU busy on a latency-bound loop (measured 0.15 ms for 4096 boards at A = 432).  Split: a logits kernel
+// over (board tile, group of OTG output tiles) -> 4-7x the workgroups, logits to HBM (fp32), then a softmax kernel.
+__global__ __launch_bounds__(256) void az_head_logits_kernel(HeadParams p, float *__restrict__ logits_g) {
+    __shared__ __attribute__((aligned(16))) float part[4 * OTG * 64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l15 = lane & 15;
+    const int b0 = blockIdx.x * 16, og = blockIdx.y * OTG;
+    const int K = p.HW * AZ_NET_XOUT_C, NP = p.n_ot * 16;
+    int row = b0 + l15;
+    if (row >= p.n_boards) row = p.n_boards - 1;
+    const _Float16 *xrow = p.x + (size_t)row * K + 8 * q;
+    f32x4 acc[OTG];
+#pragma unroll
+    for (int o = 0; o < OTG; o++) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int ks = wave; ks < p.ksteps; ks += 4) {
+        half8 a = *(const half8 *)(xrow + 32 * ks);
+#pragma unroll
+        for (int o = 0; o < OTG; o++)
+            if (og + o < p.n_ot) {
+                half8 w = *(const half8 *)(p.fc_w + (((size_t)(og + o) * p.ksteps + ks) * 64 + lane) * 8);
+                acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w, acc[o], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int o = 0; o < OTG; o++) *(f32x4 *)(part + ((wave * OTG + o) * 64 + lane) * 4) = acc[o];
+    __syncthreads();
+    for (int s = tid; s < OTG * 64; s += 256) {
+        int o = s >> 6, ln = s & 63;
+        if (og + o >= p.n_ot) continue;
+        f32x4 v = *(f32x4 *)(part + ((0 * OTG + o) * 64 + ln) * 4);
+#pragma unroll
+        for (int w = 1; w < 4; w++) v += *(f32x4 *)(part + ((w * OTG + o) * 64 + ln) * 4);
+        int col = 16 * (og + o) + (ln & 15);
+        float bias = p.fc_b[col];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int b = b0 + (ln >> 4) * 4 + r;
+            if (b < p.n_boards) logits_g[(size_t)b * NP + col] = v[r] + bias;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void az_head_softmax_kernel(HeadParams p, const float *__restrict__ logits_g) {
+    const int tid = threadIdx.x, brd = tid >> 4, sub = tid & 15;
+    const int b = blockIdx.x * 16 + brd, NP = p.n_ot * 16;
+    const float *lg = logits_g + (size_t)(b < p.n_boards ? b : p.n_boards - 1) * NP;
+    float mx = -INFINITY;
+    for (int o = sub; o < p.A; o += 16) mx = fmaxf(mx, lg[o]);
+#pragma unroll
+    for (int off = 8; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
+    float sum = 0.f;
+    for (int o = sub; o < p.A; o += 16) sum += __expf(lg[o] - mx);
+#pragma unroll
+    for (int off = 8; off; off >>= 1) sum += __shfl_xor(sum, off, 16);
+    if (b < p.n_boards) {
+        float inv = 1.f / sum;
+        float *out = p.priors + (size_t)b * p.A;
+        for (int o = sub; o < p.A; o += 16) out[o] = __expf(lg[o] - mx) * inv;
+        if (sub == 0) p.values[b] = tanhf(lg[p.A]);
+    }
+}
+
 // ================================================================================================
 struct az_net {
     az_net_desc d;
     std::string err;
     _Float16 *conv_w = nullptr, *fc_w = nullptr, *xout = nullptr;
-    float *epi = nullptr, *fc_b = nullptr, *skip_w = nullptr;
+    float *epi = nullptr, *fc_b = nullptr, *skip_w = nullptr, *logits = nullptr;
     float in_affine[16];
     int max_boards = 0;
     int bpw_max = 0, lds_head = 0, n_ot = 0;
@@ -422,6 +484,7 @@ extern "C" int az_net_destroy(az_net *n) {
     (void)hipFree(n->epi);
     (void)hipFree(n->fc_b);
     (void)hipFree(n->skip_w);
+    (void)hipFree(n->logits);
     delete n;
     return AZ_OK;
 }
@@ -548,6 +611,9 @@ extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
     size_t bytes = (size_t)max_boards * n->d.rows * n->d.cols * AZ_NET_XOUT_C * 2;
     NCHK(n, hipMalloc((void **)&n->xout, bytes));
     NCHK(n, hipMemset(n->xout, 0, bytes));
+    if (n->logits) (void)hipFree(n->logits);
+    n->logits = nullptr;
+    if (n->n_ot > OTG) NCHK(n, hipMalloc((void **)&n->logits, (size_t)max_boards * n->n_ot * 16 * sizeof(float)));
     n->max_boards = max_boards;
     return AZ_OK;
 }
@@ -641,14 +707,17 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     hp.fc_b = n->fc_b;
     hp.priors = priors;
     hp.values = values;
-    {
+    if (n->n_ot > OTG) { // large action space: logits over (board tile x output-tile group), then softmax
+        hipLaunchKernelGGL(az_head_logits_kernel, dim3((n_boards + 15) / 16, (n->n_ot + OTG - 1) / OTG), dim3(256), 0, st, hp, n->logits);
+        hipLaunchKernelGGL(az_head_softmax_kernel, dim3((n_boards + 15) / 16), dim3(256), 0, st, hp, (const float *)n->logits);
+    } else {
         static bool head_attr[16] = {false};
         if (!head_attr[n->d.device & 15]) {
             NCHK(n, hipFuncSetAttribute((const void *)az_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             head_attr[n->d.device & 15] = true;
         }
+        hipLaunchKernelGGL(az_head_kernel, dim3((n_boards + 15) / 16), dim3(256), n->lds_head, st, hp);
     }
-    hipLaunchKernelGGL(az_head_kernel, dim3((n_boards + 15) / 16), dim3(256), n->lds_head, st, hp);
     NCHK(n, hipGetLastError());
     return AZ_OK;
 }

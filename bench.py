@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--blocks", type=int, default=10)
     ap.add_argument("--filters", type=int, default=50)
+    ap.add_argument("--weights", default="random", choices=["random", "checkpoint"],
+                    help="checkpoint = the reference's shipped 5-block x 50 nets (tests/golden/checkpoint_*.npz; connect_four and "
+                         "breakthrough 6x6 only): realistic priors, game lengths and tree shapes; overrides --blocks/--filters")
     ap.add_argument("--net", default="fused", choices=["fused", "torch"],
                     help="fused = csrc/az_net.hip MFMA tower (fp16 operands, fp32 accumulate); torch = nn.Module under PyTorch-ROCm")
     ap.add_argument("--dtype", default=None, choices=["f32", "f16", "bf16"], help="torch backend only (fused is f16)")
@@ -134,7 +137,14 @@ def main():
     H, Wd = game.rows, game.cols
     G, S, K, Wm = args.slots, args.playouts, args.steps, args.warmup
     torch.manual_seed(args.seed)
-    net = Net(game.information_state_normalized_vector_shape(), A, n_blocks=args.blocks, n_filters=args.filters)
+    if args.weights == "checkpoint":
+        from alphazero_openspiel_amd.network import load_npz_checkpoint
+        tag = {"connect_four": "connect_four", "breakthrough(rows=6,columns=6)": "breakthrough6"}[game.name]
+        net = load_npz_checkpoint(os.path.join(ROOT, "tests", "golden", "checkpoint_%s.npz" % tag),
+                                  game.information_state_normalized_vector_shape(), A)
+        args.blocks, args.filters = net.n_blocks, net.n_filts
+    else:
+        net = Net(game.information_state_normalized_vector_shape(), A, n_blocks=args.blocks, n_filters=args.filters)
     if args.net == "fused":
         from alphazero_openspiel_amd.fusednet import FusedNet
         args.dtype = "f16"
@@ -251,7 +261,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s, %d sims/move, %d-block x %d-filter ResNet, %d concurrent games per GPU"
                                    % (game.name, S, args.blocks, args.filters, G),
-                       "weights": "random-init (torch.manual_seed), eval-mode BN", "net_backend": args.net,
+                       "weights": ("random-init (torch.manual_seed), eval-mode BN" if args.weights == "random" else
+                                   "the reference's shipped checkpoint (5-block x 50)"), "net_backend": args.net,
                        "tree_dtype": "f64", "c_puct": 2.5, "temperature": 1.0, "dirichlet_alpha": 0.3,
                        "parallelism": "games sharded over %d GPU(s), no collective inside the search" % world,
                        "hip_graph": graph is not None},
