@@ -345,6 +345,15 @@ __global__ __launch_bounds__(256) void az_head_kernel(HeadParams p) {
         f32x4 acc[OTG];
 #pragma unroll
         for (int o = 0; o < OTG; o++) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.n_ot == 1) { // small action space (connect_four): one output tile -> a pure chain of load, load, MFMA per
+                           // k-step; unrolled so that the loads of several k-steps are in flight together
+#pragma unroll 8
+            for (int ks = wave; ks < p.ksteps; ks += 4) {
+                half8 a = *(const half8 *)(xrow + 32 * ks);
+                half8 w = *(const half8 *)(p.fc_w + ((size_t)ks * 64 + lane) * 8);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w, acc[0], 0, 0, 0);
+            }
+        } else
         for (int ks = wave; ks < p.ksteps; ks += 4) {
             half8 a = *(const half8 *)(xrow + 32 * ks);
 #pragma unroll
