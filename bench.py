@@ -252,6 +252,16 @@ def main():
     tree_gbs = sims_tick * b_sim / t_tree / 1e9
     peak = MFMA_PEAK_TFLOPS[args.dtype]
 
+    # HBM bytes per launch measured with rocprofv3 PMC counters on this exact command (separate FETCH_SIZE and
+    # WRITE_SIZE passes, profiles/r1_hbm_traffic_pmc.txt).  They cannot be collected from inside this process, so
+    # they are quoted only when the workload is the profiled one.  Net: FETCH_SIZE doubled (wide 16-B/lane streams
+    # are reported at half size on gfx950, MI355X_MICROARCH.md); tree: uncorrected (narrow accesses, uncalibrated).
+    traffic_net = traffic_tree = None
+    if (game.name, G, S, args.blocks, args.filters, args.net, args.weights) == ("connect_four", 4096, 400, 10, 50,
+                                                                                "fused", "random"):
+        traffic_net = 2 * (6709.5e3 + 11130.0e3) + 21738.8e3 + 128.0e3
+        traffic_tree = (9736.8e3 + 156.9e3) + (7032.8e3 + 17.5e3)
+
     if rank == 0:
         plies_per_game = moves_all / max(1.0, games_all)
         out = {
@@ -275,11 +285,12 @@ def main():
             "roofline": {"bound": "mfma", "kernel": ("az_tower_kernel + az_head_kernel" if args.net == "fused" else "torch Net.forward (MIOpen)")
                                    + ", %d boards/launch" % G,
                          "achieved": net_tflops, "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
-                         "traffic": None, "flops_per_eval": f_eval, "ms_per_launch": 1e3 * t_net,
+                         "traffic": traffic_net, "traffic_unit": "bytes/launch (PMC, profiles/r1_hbm_traffic_pmc.txt)",
+                         "flops_per_eval": f_eval, "ms_per_launch": 1e3 * t_net,
                          "batch_fill": evals_tick / G},
             "roofline_tree": {"bound": "hbm", "kernel": "az_advance_kernel + az_move_kernel",
                               "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": tree_gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_sim": b_sim,
+                              "frac": tree_gbs / HBM_PEAK_GBS, "traffic": traffic_tree, "bytes_per_sim": b_sim,
                               "sims_per_launch": sims_tick, "ms_per_launch": 1e3 * t_tree},
         }
         if world == 1 and not args.no_cpu_baseline:
