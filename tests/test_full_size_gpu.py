@@ -1,0 +1,144 @@
+"""The headline workload at FULL size (BASELINE.json configs[1]: connect_four, 400 sims/move, 10-block x 50 net,
+4096 concurrent games on one GPU), checked through properties that do not need an oracle run of that size:
+
+* rules: every recorded game replays move by move through the host rules (legal moves, recorded bitboards, terminal
+  at the end, recorded return), the children of every root are exactly the legal actions in ascending order;
+* value targets: z alternates sign along a game and equals the final return seen by the player to move;
+* conservation of visits (mcts.py:126-153,192-203 with keep_search_tree): the first search of a game leaves exactly S
+  visits below the root, and after a move to a child with N_c visits the next root carries S + max(N_c - 1, 0);
+* slot-count invariance: the RNG streams are keyed by game id, the net evaluates each board independently, so the
+  same seed played on 4096 slots and on 1024 slots (four refills) yields identical records, bit for bit;
+* replay store at that size: the number of unique examples equals the number of distinct action histories, the
+  unique list is in first-occurrence order, singletons keep the reference's pi arithmetic exactly, and the mean
+  value target over all examples is preserved by the averaging (count-weighted).
+"""
+import numpy as np
+import pytest
+import torch
+
+from alphazero_openspiel_amd import games
+
+pytestmark = pytest.mark.gpu
+
+S, G, N_GAMES = 400, 4096, 4096
+
+
+def _play(n_slots, n_games, seed, keep_engine=False):
+    from alphazero_openspiel_amd import engine as E, fusednet
+    from alphazero_openspiel_amd.network import Net
+    torch.manual_seed(0)
+    net = Net([3, 6, 7], 7, n_blocks=10, n_filters=50).eval()
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots)
+    eng = E.SelfPlayEngine("connect_four", n_slots, n_playouts=S, max_games=n_games, seed=seed, device=0)
+    prog = E.run_selfplay(eng, fn, n_games, use_graph=True)
+    assert prog["games_done"] == n_games and prog["error_flags"] == 0
+    ex = eng.export()
+    if keep_engine:
+        return ex, prog, eng, fn
+    eng.close()
+    fn.close()
+    return ex, prog
+
+
+@pytest.fixture(scope="module")
+def full_run():
+    ex, prog, eng, fn = _play(G, N_GAMES, seed=2024, keep_engine=True)
+    yield ex, prog, eng
+    eng.close()
+    fn.close()
+
+
+def test_full_size_games_obey_the_rules_and_conserve_visits(full_run):
+    ex, prog, _ = full_run
+    game = games.load_game("connect_four")
+    n_first_searches = 0
+    for g in range(N_GAMES):
+        n = int(ex["game_len"][g])
+        assert 7 <= n <= 42
+        s = game.new_initial_state()
+        prev_child_visits = None
+        for i in range(n):
+            assert [int(x) for x in ex["states"][g, i]] == list(s.bb)
+            legal = s.legal_actions()
+            nc = int(ex["n_children"][g, i])
+            assert ex["child_action"][g, i, :nc].tolist() == legal
+            visits = ex["child_visits"][g, i, :nc].astype(np.int64)
+            total = int(visits.sum())
+            if prev_child_visits is None:
+                assert total == S
+                n_first_searches += 1
+            else:
+                assert total == S + max(prev_child_visits - 1, 0)
+            a = int(ex["move"][g, i])
+            assert a in legal and visits[legal.index(a)] > 0  # temperature sampling never picks an unvisited child
+            prev_child_visits = int(visits[legal.index(a)])
+            s.apply_action(a)
+        assert s.is_terminal()
+        ret0 = s.returns()[0]
+        assert float(ex["game_ret0"][g]) == ret0
+        z = ex["value"][g, :n]
+        want = np.where(np.arange(n) % 2 == 0, ret0, -ret0)
+        assert (z == want).all()
+    assert n_first_searches == N_GAMES
+
+
+def test_records_do_not_depend_on_the_number_of_slots(full_run):
+    ex, _, _ = full_run
+    ex_small, prog_small = _play(1024, N_GAMES, seed=2024)
+    assert prog_small["ticks"] > 0
+    for k in ("game_len", "game_ret0", "move", "n_children", "value"):
+        assert (ex[k] == ex_small[k]).all(), k
+    # beyond a game's length / a root's child count the record arrays are unspecified: compare the live part
+    live_ply = np.arange(ex["move"].shape[1])[None, :] < ex["game_len"][:, None]
+    live_child = live_ply[:, :, None] & (np.arange(ex["child_visits"].shape[2])[None, None, :]
+                                         < ex["n_children"][:, :, None])
+    assert (ex["states"][live_ply] == ex_small["states"][live_ply]).all()
+    assert (ex["child_visits"][live_child] == ex_small["child_visits"][live_child]).all()
+    assert (ex["child_action"][live_child] == ex_small["child_action"][live_child]).all()
+
+
+def test_replay_store_at_full_size(full_run):
+    from alphazero_openspiel_amd import replay
+    from alphazero_openspiel_amd.engine import pi_from_visits
+    ex, _, eng = full_run
+    rep = replay.DeviceReplay("connect_four", max_games=N_GAMES, device=0)
+    rep.set_capacity(N_GAMES)
+    rep.append_engine(eng)
+    st = rep.stats()
+    n_examples = int(ex["game_len"].sum())
+    assert st["n_games"] == N_GAMES and st["n_examples"] == n_examples
+    # distinct action histories, first occurrence and multiplicity, on the host
+    first, count, zsum = {}, {}, {}
+    flat = 0
+    for g in range(N_GAMES):
+        moves = ex["move"][g, : int(ex["game_len"][g])].tolist()
+        for i in range(len(moves)):
+            key = tuple(moves[:i])
+            if key not in first:
+                first[key] = (flat, g, i)
+                count[key] = 0
+                zsum[key] = 0.0
+            count[key] += 1
+            zsum[key] += float(ex["value"][g, i])
+            flat += 1
+    n_unique = rep.dedupe()
+    assert n_unique == len(first) < n_examples  # the empty history alone occurs 4096 times
+    u = rep.read_unique()
+    order = sorted(first.values())
+    assert u["buffer_index"].tolist() == [f for f, _, _ in order]
+    by_index = {f: key for key, (f, _, _) in first.items()}
+    checked = 0
+    weighted_z = 0.0
+    for k, (f, g, i) in enumerate(order):
+        key = by_index[f]
+        weighted_z += count[key] * u["z"][k]
+        assert abs(u["z"][k] - zsum[key] / count[key]) < 1e-12
+        if count[key] == 1 and checked < 2000:
+            nc = int(ex["n_children"][g, i])
+            want = pi_from_visits(ex["child_action"][g, i, :nc].astype(np.int64), ex["child_visits"][g, i, :nc], 7)
+            assert u["pi"][k].tolist() == want
+            checked += 1
+    assert checked > 0
+    assert abs(weighted_z - float(sum(ex["value"][g, : int(ex["game_len"][g])].sum() for g in range(N_GAMES)))) < 1e-6
+    assert np.abs(u["pi"].sum(1) - 1).max() < 1e-12
+    rep.close()
