@@ -20,6 +20,7 @@
 
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/az_engine.h"
@@ -84,16 +85,30 @@ __device__ __forceinline__ void wait_lgkm(int n) {
 __device__ __forceinline__ void lds_read128(half8 &dst, unsigned lds_byte_addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_byte_addr));
 }
+// same, with a compile-time byte offset in the instruction's 16-bit offset field (no address arithmetic in the loop)
+template <int OFF> __device__ __forceinline__ void lds_read128_off(half8 &dst, unsigned lds_byte_addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
+}
 #ifdef AZ_ABL_NOA
-#define READ_A(dst, addr) asm volatile("" : "=v"(dst) : "v"(addr))
+#define READ_A(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr))
 #else
-#define READ_A(dst, addr) lds_read128(dst, addr)
+#define READ_A(dst, addr, off) lds_read128_off<(off)>(dst, addr)
 #endif
 #ifdef AZ_ABL_NOB
 #define READ_B(dst, addr) asm volatile("" : "=v"(dst) : "v"(addr))
+#define READ_B_OFF(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr))
 #else
 #define READ_B(dst, addr) lds_read128(dst, addr)
+#define READ_B_OFF(dst, addr, off) lds_read128_off<(off)>(dst, addr)
 #endif
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 // LDS image of one wave: 7 channel-octet planes [rcells][8 fp16], plane stride a multiple of 256 B;
 // cell = board*cells + (y+1)*rs + (x+1), halo cells stay zero.  Bank behaviour of the B-fragment ds_read_b128: a lane
@@ -102,7 +117,9 @@ __device__ __forceinline__ void lds_read128(half8 &dst, unsigned lds_byte_addr) 
 // LDS cycles were conflicts), so for W <= 7 a column tile is TWO WHOLE ROWS at row stride 8: lane l15 -> row 2t + (l15>>3),
 // x = l15 & 7 = 16 consecutive cells (x = 7 is the shared halo column: a padding lane).  connect_four: 6 tiles per
 // 2 boards either way.  Wider boards keep the generic packing (n = 16*nt + l15 over positions, 2-way conflicts).
-template <int NT, int CK, int WAVES>
+// RP1: row-pair tiles with one board per wave: column tile nt sits exactly nt * 256 bytes after tile 0, so a B-fragment
+// address is one precomputed register per k-step plus an immediate.
+template <int NT, int CK, int WAVES, bool RP1>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int CHUNK_B = CK * 4 * 64 * 16;
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             b = nt / p.tpb;
             y = 2 * (nt - b * p.tpb) + (l15 >> 3);
             x = l15 & 7;
-            ok = x < p.W && y < p.H;
+            ok = x < p.W && y < p.H && b < p.bpw; // (a kernel with more tiles than the boards need masks the rest)
         } else {
             int n = nt * 16 + l15;
             b = n / p.HW;
@@ -149,6 +166,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
         int tap = g / 7, c8 = g - tap * 7;
         int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         koff[ks] = g == 63 ? 0 : (dy * p.rs + dx) * OCT_B + c8 * plane_b; // group 63: zero weights, any finite data
+        if (RP1) koff[ks] += (int)lds_base + pos_addr[0];                 // the full LDS address of tile 0's fragment
     }
 
     f32x4 acc[4][NT], xres[4][NT];
@@ -202,11 +220,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
 
     int chunk = 0;
     constexpr int PARTS = AZ_NET_KSTEPS / CK;
+    static_assert(CK * 4 * 1024 <= 65536, "A-fragment offsets (relative to the chunk base) must fit the ds offset field");
     static_assert(CK % 2 == 0, "fragment buffer parity relies on an even chunk length");
     for (int conv = 0; conv < p.n_convs; conv++) {
         half8 a[2][4], b[2][NT]; // fragment double buffer: k-step s+1 is fetched while s is multiplied
-#pragma unroll
-        for (int part = 0; part < PARTS; part++, chunk++) {
+        static_for<PARTS>([&](auto part_c) {
+            constexpr int part = decltype(part_c)::value;
             // The weight fragments are read by untracked asm, so hipcc sees no consumer of the LDS-DMA and would NOT wait
             // for it: wait by hand.  After the barrier every wave's pieces of this chunk have landed and the other
             // buffer is free for the next chunk's DMA.
@@ -222,49 +241,55 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             // Fragment reads are inline asm so that the compiler neither sinks them next to their first use nor
             // inserts its own lgkmcnt(0) (left alone it waits every 8 MFMAs: 34 % MFMA utilisation).  Order:
             //   wait(all of k-step ksl) ; for each read of k-step ksl+1: {ds_read ; MFMA of ksl} ; remaining MFMAs
-            // so a read has most of an MFMA block (16 cycles per MFMA) to land before the next wait.
+            // so a read has most of an MFMA block (16 cycles per MFMA) to land before the next wait.  All loop indices
+            // are compile-time (static_for), so fragment offsets sit in the instructions' offset fields.
             const unsigned wbl = lds_base + (chunk & 1) * CHUNK_B + lane * 16;
+            // B fragment of column tile nt in k-step ks (ks compile-time)
+            auto read_b = [&](half8 &dst, auto ks_c, auto nt_c) {
+                constexpr int ks = decltype(ks_c)::value, nt = decltype(nt_c)::value;
+                if constexpr (RP1) READ_B_OFF(dst, (unsigned)koff[ks], nt * 256);
+                else READ_B(dst, lds_base + pos_addr[nt] + opaque(koff[ks])); // opaque: keep the NT*16 sums out of LICM's hands
+            };
             // Read order inside a k-step: A0..A3, B0, B1, ... (read index: A_mt = mt, B_nt = 4 + nt).  LDS returns in
             // order, so before the MFMAs of column tile nt it is enough to wait until at most (reads issued after
             // B_nt) are outstanding: counted s_waitcnt instead of lgkmcnt(0).
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) READ_A(a[0][mt], wbl + mt * 1024);
-            if (part == 0) { // later chunks of a conv had their B fragments fetched before the barrier
-                int ko = opaque(koff[0]); // keep pos_addr + koff out of LICM's hands (it would hoist NT*16 sums)
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) READ_B(b[0][nt], lds_base + pos_addr[nt] + ko);
-            }
-#pragma unroll
-            for (int ksl = 0; ksl < CK; ksl++) {
-                const int cur = ksl & 1, nxt = cur ^ 1;
-                const bool more_here = ksl + 1 < CK;                   // next k-step is in this chunk: A and B
-                const bool more_next = !more_here && part + 1 < PARTS; // next k-step is in the next chunk: B only
-                const int n_next = more_here ? NT + 4 : (more_next ? NT : 0); // reads to issue during this k-step
-                const bool first_of_chunk = ksl == 0;
-                const int ko = (more_here || more_next) ? opaque(koff[part * CK + ksl + 1]) : 0;
-                int issued_next = 0;
-#pragma unroll
-                for (int j = 0; j < 4 * NT; j++) {
-                    const int nt = j >> 2, mt = j & 3;
-                    if (mt == 0) {
+            static_for<4>([&](auto mt_c) {
+                constexpr int mt = decltype(mt_c)::value;
+                READ_A(a[0][mt], wbl, mt * 1024);
+            });
+            if constexpr (part == 0) // later chunks of a conv had their B fragments fetched before the barrier
+                static_for<NT>([&](auto nt_c) { read_b(b[0][decltype(nt_c)::value], std::integral_constant<int, 0>{}, nt_c); });
+            static_for<CK>([&](auto ksl_c) {
+                constexpr int ksl = decltype(ksl_c)::value;
+                constexpr int cur = ksl & 1, nxt = cur ^ 1;
+                constexpr bool more_here = ksl + 1 < CK;                   // next k-step is in this chunk: A and B
+                constexpr bool more_next = !more_here && part + 1 < PARTS; // next k-step is in the next chunk: B only
+                constexpr int n_next = more_here ? NT + 4 : (more_next ? NT : 0); // reads to issue during this k-step
+                constexpr bool first_of_chunk = ksl == 0;
+                constexpr int ks_next = (more_here || more_next) ? part * CK + ksl + 1 : 0;
+                static_for<4 * NT>([&](auto j_c) {
+                    constexpr int j = decltype(j_c)::value;
+                    constexpr int nt = j >> 2, mt = j & 3;
+                    constexpr int issued_next = j < n_next ? j : n_next; // one read of the next k-step per MFMA so far
+                    if constexpr (mt == 0) {
                         // reads of THIS k-step still allowed in flight: those after B_nt; plus all reads of the next one
                         // issued so far.  (First k-step of a later chunk: its B came before the barrier, its A after ->
                         // everything of this k-step must be in.)
-                        int after = (first_of_chunk && part > 0) ? 0 : NT - 1 - nt;
+                        constexpr int after = (first_of_chunk && part > 0) ? 0 : NT - 1 - nt;
                         wait_lgkm(after + issued_next);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (issued_next < n_next) { // one read of the next k-step per MFMA, in the same order
-                        const int r = more_here ? issued_next : issued_next + 4; // B-only prefetch skips the A slots
-                        if (r < 4) READ_A(a[nxt][r], wbl + ((ksl + 1) * 4 + r) * 1024);
-                        else READ_B(b[nxt][r - 4], lds_base + pos_addr[r - 4] + ko);
-                        issued_next++;
+                    if constexpr (j < n_next) { // one read of the next k-step per MFMA, in the same order
+                        constexpr int r = more_here ? j : j + 4; // B-only prefetch skips the A slots
+                        if constexpr (r < 4) READ_A(a[nxt][r], wbl, ((ksl + 1) * 4 + r) * 1024);
+                        else read_b(b[nxt][r - 4], std::integral_constant<int, ks_next>{}, std::integral_constant<int, r - 4>{});
                     }
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
+                });
+            });
+            chunk++;
+        });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // nothing of mine in flight when the epilogue touches LDS
         // ---- epilogue of this conv (the wave's own boards only: no barrier needed) ------------------------
         // The accumulators were initialised with this conv's bias, so: conv1: u = lrelu(acc); conv2: x += acc,
@@ -627,15 +652,20 @@ extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
     return AZ_OK;
 }
 
-template <int NT, int CK, int WAVES> static hipError_t launch_tower(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
+template <int NT, int CK, int WAVES, bool RP1> static hipError_t launch_tower_rp(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
     static bool attr_set[16] = {false};
     if (!attr_set[n->d.device & 15]) {
-        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT, CK, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT, CK, WAVES, RP1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (s != hipSuccess) return s;
         attr_set[n->d.device & 15] = true;
     }
-    hipLaunchKernelGGL((az_tower_kernel<NT, CK, WAVES>), dim3(grid), dim3(WAVES * 64), lds, st, tp);
+    hipLaunchKernelGGL((az_tower_kernel<NT, CK, WAVES, RP1>), dim3(grid), dim3(WAVES * 64), lds, st, tp);
     return hipGetLastError();
+}
+template <int NT, int CK, int WAVES> static hipError_t launch_tower(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
+    // row-pair tiles (row stride 8), one board per wave, every tile of the wave on that board
+    if (tp.tpb && tp.bpw == 1 && tp.rs == 8 && tp.tpb <= NT) return launch_tower_rp<NT, CK, WAVES, true>(n, tp, grid, lds, st);
+    return launch_tower_rp<NT, CK, WAVES, false>(n, tp, grid, lds, st);
 }
 template <int NT> static hipError_t launch_tower_ck(const az_net *n, const TowerParams &tp, int grid, const TowerGeom &g, hipStream_t st) {
     if constexpr (NT <= 3) {
