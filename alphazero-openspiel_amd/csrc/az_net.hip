@@ -7,7 +7,8 @@
 //     rows), rewritten in place layer after layer; the fp32 residual stream lives in registers.
 //   * every 3x3 conv is an implicit GEMM on v_mfma_f32_16x16x32_f16:  D[co][n] += Wp[co][k] * Act[k][n],
 //     n = (board, position) over the wave's boards, k = 64 groups x 8 channels (group -> tap, channel
-//     octet; group 63 = raw input planes, carries block 1's 1x1 skip).  M = 64 output channels (4 tiles),
+//     octet; group 63 = zero padding); conv 0, which sees only the input planes, is compacted on upload to
+//     16 groups (9 taps x one octet) = 4 k-steps.  M = 64 output channels (4 tiles),
 //     so the accumulator of lane l holds 4 CONSECUTIVE channels of one position: the epilogue
 //     (bias, LeakyReLU, next BN scale/shift) packs them to fp16 and writes 8 bytes back to the image.
 //   * weights are the A operand, shared by all waves of the workgroup: streamed L2 -> LDS by
@@ -35,6 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   AZ_ABL_NOEPI   no epilogue arithmetic / LDS writes        AZ_ABL_NOB    no B-fragment (activation) LDS reads
 //   AZ_ABL_NOA     no A-fragment (weight) LDS reads           AZ_ABL_NODMA  no weight DMA and no chunk barrier
 #define OCT_B 16 // one cell of one channel-octet plane: 8 fp16
+#define AZ_NET_K0STEPS 4 // k-steps of conv 0 on the device (9 taps x the one octet holding the input planes, padded to 16 groups)
 #define N_OCT 7  // 56 channels
 
 struct TowerParams {
@@ -168,6 +170,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
         koff[ks] = g == 63 ? 0 : (dy * p.rs + dx) * OCT_B + c8 * plane_b; // group 63: zero weights, any finite data
         if (RP1) koff[ks] += (int)lds_base + pos_addr[0];                 // the full LDS address of tile 0's fragment
     }
+    // conv 0 reads the 4 input planes only (octet 0): K = 9 taps x 1 octet, packed as ONE 4-k-step chunk
+    // (group g < 9 = tap g of octet 0, groups 9..15 zero weights) instead of 16 k-steps that are 6/7 zeros.
+    int koff0[AZ_NET_K0STEPS];
+#pragma unroll
+    for (int ks = 0; ks < AZ_NET_K0STEPS; ks++) {
+        int g = 4 * ks + q;
+        int dy = g / 3 - 1, dx = g - (g / 3) * 3 - 1;
+        koff0[ks] = g < 9 ? (dy * p.rs + dx) * OCT_B : 0;
+        if (RP1) koff0[ks] += (int)lds_base + pos_addr[0];
+    }
 
     f32x4 acc[4][NT], xres[4][NT];
     // ---- prologue: a = lrelu(bn1(x0)) -> octet 0; block-1 skip conv3(x0) in fp32 -> residual stream --------
@@ -204,27 +216,40 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
         }
     }
 
-    // ---- weight stream: chunk c (CK k-steps) -> buffer c&1, by LDS-DMA (global_load_lds, 16 B/lane) ----------
-    const int n_chunks = p.n_convs * (AZ_NET_KSTEPS / CK);
-    auto issue_chunk = [&](int c) {
-        const unsigned char *src = (const unsigned char *)p.conv_w + (size_t)c * CHUNK_B;
-        unsigned char *dst = lds + (c & 1) * CHUNK_B;
+    // ---- weight stream: chunk c -> buffer c&1, by LDS-DMA (global_load_lds, 16 B/lane).  Chunk 0 = conv 0 (4 k-steps,
+    // 16 KiB), chunk c >= 1 = CK k-steps of the 16-k-step convs that follow, contiguous in the device buffer.
+    constexpr int PARTS = AZ_NET_KSTEPS / CK;
+    constexpr int C0_B = AZ_NET_K0STEPS * 4 * 64 * 16;
+    static_assert(CK % 2 == 0 && AZ_NET_K0STEPS % 2 == 0, "fragment buffer parity relies on an even chunk length");
+    static_assert(CK * 4 * 1024 <= 65536, "A-fragment offsets (relative to the chunk base) must fit the ds offset field");
+    static_assert(C0_B <= CHUNK_B && C0_B % (WAVES * 1024) == 0 && CHUNK_B % (WAVES * 1024) == 0, "DMA pieces are one KiB per wave");
+    const int n_chunks = 1 + (p.n_convs - 1) * PARTS;
+    auto issue_bytes = [&](const unsigned char *src, unsigned char *dst, auto bytes_c) {
 #pragma unroll
-        for (int i = 0; i < CHUNK_B / (WAVES * 64 * 16); i++) {
+        for (int i = 0; i < decltype(bytes_c)::value / (WAVES * 64 * 16); i++) {
             int piece = i * WAVES + wave; // one KiB per wave-instruction, lane-linear
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
         }
     };
-    issue_chunk(0);
+    auto issue_chunk = [&](int c) { // c >= 1
+        issue_bytes((const unsigned char *)p.conv_w + C0_B + (size_t)(c - 1) * CHUNK_B, lds + (c & 1) * CHUNK_B,
+                    std::integral_constant<int, CHUNK_B>{});
+    };
+    issue_bytes((const unsigned char *)p.conv_w, lds, std::integral_constant<int, C0_B>{});
+#ifndef AZ_ABL_NODMA
+    if (wave == 0) // conv 0 has a single chunk: its epilogue parameters must land before that chunk's barrier
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(lds + p.off_epi), 16, 0, 0);
+#endif
 
     int chunk = 0;
-    constexpr int PARTS = AZ_NET_KSTEPS / CK;
-    static_assert(CK * 4 * 1024 <= 65536, "A-fragment offsets (relative to the chunk base) must fit the ds offset field");
-    static_assert(CK % 2 == 0, "fragment buffer parity relies on an even chunk length");
-    for (int conv = 0; conv < p.n_convs; conv++) {
+    // one conv = NPARTS chunks of CKL k-steps (kf: this lane's k-group offsets) + its epilogue
+    auto conv_step = [&](int conv, auto nparts_c, auto ckl_c, const auto &kf, auto is_first_c) {
+        constexpr int NPARTS = decltype(nparts_c)::value, CKL = decltype(ckl_c)::value;
+        constexpr bool IS_FIRST = decltype(is_first_c)::value;
         half8 a[2][4], b[2][NT]; // fragment double buffer: k-step s+1 is fetched while s is multiplied
-        static_for<PARTS>([&](auto part_c) {
+        static_for<NPARTS>([&](auto part_c) {
             constexpr int part = decltype(part_c)::value;
             // The weight fragments are read by untracked asm, so hipcc sees no consumer of the LDS-DMA and would NOT wait
             // for it: wait by hand.  After the barrier every wave's pieces of this chunk have landed and the other
@@ -233,8 +258,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (chunk + 1 < n_chunks) issue_chunk(chunk + 1);
-            if (part == 0 && wave == 0) // this conv's epilogue parameters ride the same DMA path into a 2-slot ring; they
-                                        // land before the next chunk barrier, i.e. long before the epilogue reads them
+            if (!IS_FIRST && part == 0 && wave == 0) // this conv's epilogue parameters ride the same DMA path into a 2-slot ring;
+                                                     // they land before the next chunk barrier, long before the epilogue reads them
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + (size_t)conv * 1024 + lane * 16),
                                                  (__attribute__((address_space(3))) void *)(lds + p.off_epi + (conv & 1) * 1024), 16, 0, 0);
 #endif
@@ -247,8 +272,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             // B fragment of column tile nt in k-step ks (ks compile-time)
             auto read_b = [&](half8 &dst, auto ks_c, auto nt_c) {
                 constexpr int ks = decltype(ks_c)::value, nt = decltype(nt_c)::value;
-                if constexpr (RP1) READ_B_OFF(dst, (unsigned)koff[ks], nt * 256);
-                else READ_B(dst, lds_base + pos_addr[nt] + opaque(koff[ks])); // opaque: keep the NT*16 sums out of LICM's hands
+                if constexpr (RP1) READ_B_OFF(dst, (unsigned)kf[ks], nt * 256);
+                else READ_B(dst, lds_base + pos_addr[nt] + opaque(kf[ks])); // opaque: keep the NT*16 sums out of LICM's hands
             };
             // Read order inside a k-step: A0..A3, B0, B1, ... (read index: A_mt = mt, B_nt = 4 + nt).  LDS returns in
             // order, so before the MFMAs of column tile nt it is enough to wait until at most (reads issued after
@@ -259,14 +284,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             });
             if constexpr (part == 0) // later chunks of a conv had their B fragments fetched before the barrier
                 static_for<NT>([&](auto nt_c) { read_b(b[0][decltype(nt_c)::value], std::integral_constant<int, 0>{}, nt_c); });
-            static_for<CK>([&](auto ksl_c) {
+            static_for<CKL>([&](auto ksl_c) {
                 constexpr int ksl = decltype(ksl_c)::value;
                 constexpr int cur = ksl & 1, nxt = cur ^ 1;
-                constexpr bool more_here = ksl + 1 < CK;                   // next k-step is in this chunk: A and B
-                constexpr bool more_next = !more_here && part + 1 < PARTS; // next k-step is in the next chunk: B only
+                constexpr bool more_here = ksl + 1 < CKL;                   // next k-step is in this chunk: A and B
+                constexpr bool more_next = !more_here && part + 1 < NPARTS; // next k-step is in the next chunk: B only
                 constexpr int n_next = more_here ? NT + 4 : (more_next ? NT : 0); // reads to issue during this k-step
                 constexpr bool first_of_chunk = ksl == 0;
-                constexpr int ks_next = (more_here || more_next) ? part * CK + ksl + 1 : 0;
+                constexpr int ks_next = (more_here || more_next) ? part * CKL + ksl + 1 : 0;
                 static_for<4 * NT>([&](auto j_c) {
                     constexpr int j = decltype(j_c)::value;
                     constexpr int nt = j >> 2, mt = j & 3;
@@ -338,10 +363,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                 }
             }
         };
-        if (!(conv & 1)) epilogue(std::integral_constant<int, 0>{});
-        else if (conv != p.n_convs - 1) epilogue(std::integral_constant<int, 1>{});
-        else epilogue(std::integral_constant<int, 2>{});
-    }
+        if constexpr (IS_FIRST) epilogue(std::integral_constant<int, 0>{});
+        else {
+            if (!(conv & 1)) epilogue(std::integral_constant<int, 0>{});
+            else if (conv != p.n_convs - 1) epilogue(std::integral_constant<int, 1>{});
+            else epilogue(std::integral_constant<int, 2>{});
+        }
+    };
+    conv_step(0, std::integral_constant<int, 1>{}, std::integral_constant<int, AZ_NET_K0STEPS>{}, koff0, std::true_type{});
+    for (int conv = 1; conv < p.n_convs; conv++)
+        conv_step(conv, std::integral_constant<int, PARTS>{}, std::integral_constant<int, CK>{}, koff, std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -610,7 +641,22 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
             rc = AZ_E_NOMEM;
         }
     };
-    up((void **)&n->conv_w, d.conv_w, cw);
+    {   // device layout: [conv 0 compacted to AZ_NET_K0STEPS k-steps][conv 1 ..][..] (ABI layout: 16 k-steps each).
+        // Conv 0 sees the input planes only (channel octet 0), i.e. ABI groups 7*tap; they become groups 0..8.
+        const size_t conv_b = (size_t)AZ_NET_KSTEPS * 4 * 64 * 8 * 2, c0_b = (size_t)AZ_NET_K0STEPS * 4 * 64 * 8 * 2;
+        std::vector<unsigned char> dev(c0_b + cw - conv_b, 0);
+        const unsigned char *src = (const unsigned char *)d.conv_w;
+        for (int ks = 0; ks < AZ_NET_K0STEPS; ks++)
+            for (int mt = 0; mt < 4; mt++)
+                for (int lane = 0; lane < 64; lane++) {
+                    int g = 4 * ks + (lane >> 4);
+                    if (g >= 9) continue;
+                    int go = 7 * g, oks = go >> 2, olane = (go & 3) * 16 + (lane & 15);
+                    memcpy(&dev[(((size_t)ks * 4 + mt) * 64 + lane) * 16], src + (((size_t)oks * 4 + mt) * 64 + olane) * 16, 16);
+                }
+        memcpy(&dev[c0_b], src + conv_b, cw - conv_b);
+        up((void **)&n->conv_w, dev.data(), dev.size());
+    }
     {   // [conv][3][64] (ABI) -> [conv][4][64] with the NEXT conv's bias in row 3 (what the kernel's ring slot holds)
         int nc = 2 * d.n_blocks;
         std::vector<float> e4((size_t)nc * 256, 0.f);
