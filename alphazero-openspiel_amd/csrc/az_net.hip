@@ -92,6 +92,10 @@ template <int OFF> __device__ __forceinline__ void lds_read128_off(half8 &dst, u
     static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
 }
+template <int OFF> __device__ __forceinline__ void lds_read_f4_off(f32x4 &dst, unsigned lds_byte_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
+}
+__device__ __forceinline__ void keep_alive(const f32x4 &v) { asm volatile("" ::"v"(v)); }
 #ifdef AZ_ABL_NOA
 #define READ_A(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr))
 #else
@@ -249,6 +253,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
         constexpr int NPARTS = decltype(nparts_c)::value, CKL = decltype(ckl_c)::value;
         constexpr bool IS_FIRST = decltype(is_first_c)::value;
         half8 a[2][4], b[2][NT]; // fragment double buffer: k-step s+1 is fetched while s is multiplied
+        // This conv's epilogue parameters for the lane's 4 x 4 channels (scale, shift, next conv's bias): fetched from the
+        // ring during the LAST k-step, when the other fragment buffer is dead, so the epilogue never waits on LDS.
+        f32x4 ep_sc[4], ep_sh[4], ep_nb[4];
+        const unsigned ep_base = lds_base + p.off_epi + (conv & 1) * 1024 + q * 16;
         static_for<NPARTS>([&](auto part_c) {
             constexpr int part = decltype(part_c)::value;
             // The weight fragments are read by untracked asm, so hipcc sees no consumer of the LDS-DMA and would NOT wait
@@ -292,6 +300,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                 constexpr int n_next = more_here ? NT + 4 : (more_next ? NT : 0); // reads to issue during this k-step
                 constexpr bool first_of_chunk = ksl == 0;
                 constexpr int ks_next = (more_here || more_next) ? part * CKL + ksl + 1 : 0;
+                constexpr bool last_of_conv = !more_here && !more_next;
+                // (conv 0 is always a conv1-type epilogue: next bias only.  An asynchronous read into a register nothing
+                // consumes would let the compiler hand that register to something else while the data is still in flight.)
+                constexpr int n_ep = last_of_conv ? (IS_FIRST ? 4 : 12) : 0; // younger reads the counted waits below must allow
+                if constexpr (last_of_conv)
+                    static_for<4>([&](auto mt_c) {
+                        constexpr int mt = decltype(mt_c)::value;
+                        if constexpr (!IS_FIRST) {
+                            lds_read_f4_off<256 + mt * 64>(ep_sc[mt], ep_base);
+                            lds_read_f4_off<512 + mt * 64>(ep_sh[mt], ep_base);
+                        }
+                        lds_read_f4_off<768 + mt * 64>(ep_nb[mt], ep_base);
+                    });
                 static_for<4 * NT>([&](auto j_c) {
                     constexpr int j = decltype(j_c)::value;
                     constexpr int nt = j >> 2, mt = j & 3;
@@ -301,7 +322,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                         // issued so far.  (First k-step of a later chunk: its B came before the barrier, its A after ->
                         // everything of this k-step must be in.)
                         constexpr int after = (first_of_chunk && part > 0) ? 0 : NT - 1 - nt;
-                        wait_lgkm(after + issued_next);
+                        wait_lgkm(after + issued_next + n_ep);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (j < n_next) { // one read of the next k-step per MFMA, in the same order
@@ -316,13 +337,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             chunk++;
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // nothing of mine in flight when the epilogue touches LDS
+        static_for<4>([&](auto mt_c) { // the prefetched parameters stay allocated until they have landed
+            constexpr int mt = decltype(mt_c)::value;
+            if constexpr (!IS_FIRST) {
+                keep_alive(ep_sc[mt]);
+                keep_alive(ep_sh[mt]);
+            }
+            keep_alive(ep_nb[mt]);
+        });
         // ---- epilogue of this conv (the wave's own boards only: no barrier needed) ------------------------
         // The accumulators were initialised with this conv's bias, so: conv1: u = lrelu(acc); conv2: x += acc,
         // a = lrelu(scale*x + shift).  LeakyReLU runs on the packed fp16 values (v_pk_mul_f16 + v_pk_max_f16).
         // Three straight-line variants picked ONCE per conv (left to the compiler the uniform conditions were
         // re-tested, with branches and exec masking, for every tile); stores are unconditional: padding lanes and
         // the non-existent 8th octet go to a per-lane trash slot.
-        const float *ep = (const float *)(lds + p.off_epi + (conv & 1) * 1024);
         auto epilogue = [&](auto kind) {
             constexpr int KIND = decltype(kind)::value; // 0: conv1, 1: conv2 (not last), 2: last conv
 #pragma unroll
@@ -330,12 +358,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                 const int co0 = 16 * mt + 4 * q;
                 const bool wr = (2 * mt + (q >> 1)) < N_OCT;
                 const int woff = (2 * mt + (q >> 1)) * plane_b + (q & 1) * 8; // octet plane + half of the octet
-                f32x4 sc, sh;
-                if (KIND == 1) {
-                    sc = *(const f32x4 *)(ep + 64 + co0);
-                    sh = *(const f32x4 *)(ep + 128 + co0);
-                }
-                f32x4 next_bias = *(const f32x4 *)(ep + 192 + co0);
+                const f32x4 sc = ep_sc[mt], sh = ep_sh[mt], next_bias = ep_nb[mt];
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
                     f32x4 v = acc[mt][nt];
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                             if (grow[nt] >= 0) *(half4 *)(p.xout + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = o;
                             continue;
                         }
-                        o = lrelu_h4(__builtin_convertvector(sc * xv + sh, half4));
+                        o = lrelu_h4(__builtin_convertvector(__builtin_elementwise_fma(sc, xv, sh), half4)); // one v_pk_fma_f32 per pair
                     }
                     const int wa = (wr && grow[nt] >= 0) ? pos_addr[nt] + woff : trash;
                     *(half4 *)(lds + wa) = o;
@@ -631,7 +654,7 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
         delete n;
         return AZ_E_HIP;
     }
-    size_t cw = (size_t)2 * d.n_blocks * AZ_NET_KSTEPS * 4 * 64 * 8 * 2, ep = (size_t)2 * d.n_blocks * 3 * 64 * 4;
+    size_t cw = (size_t)2 * d.n_blocks * AZ_NET_KSTEPS * 4 * 64 * 8 * 2;
     size_t fw = (size_t)n->n_ot * (HW * AZ_NET_XOUT_C / 32) * 64 * 8 * 2, fb = (size_t)n->n_ot * 16 * 4;
     int rc = AZ_OK;
     auto up = [&](void **dst, const void *src, size_t bytes) {
