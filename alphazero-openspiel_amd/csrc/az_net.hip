@@ -410,10 +410,11 @@ struct HeadParams {
 };
 
 #define OTG 8
-__global__ __launch_bounds__(256) void az_head_kernel(HeadParams p) {
+#define HEAD_NW 8 // waves per workgroup: the K reduction is split over them (memory-bound: more loads in flight per CU)
+__global__ __launch_bounds__(HEAD_NW * 64) void az_head_kernel(HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    float *part = (float *)lds;                         // [4 waves][OTG][64 lanes][4]
-    float *logits = (float *)(lds + 4 * OTG * 64 * 16); // [16][n_ot*16]
+    float *part = (float *)lds;                               // [HEAD_NW waves][OTG][64 lanes][4]
+    float *logits = (float *)(lds + HEAD_NW * OTG * 64 * 16); // [16][n_ot*16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l15 = lane & 15;
     const int b0 = blockIdx.x * 16;
     const int K = p.HW * AZ_NET_XOUT_C, NP = p.n_ot * 16;
@@ -427,13 +428,13 @@ __global__ __launch_bounds__(256) void az_head_kernel(HeadParams p) {
         if (p.n_ot == 1) { // small action space (connect_four): one output tile -> a pure chain of load, load, MFMA per
                            // k-step; unrolled so that the loads of several k-steps are in flight together
 #pragma unroll 8
-            for (int ks = wave; ks < p.ksteps; ks += 4) {
+            for (int ks = wave; ks < p.ksteps; ks += HEAD_NW) {
                 half8 a = *(const half8 *)(xrow + 32 * ks);
                 half8 w = *(const half8 *)(p.fc_w + ((size_t)ks * 64 + lane) * 8);
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w, acc[0], 0, 0, 0);
             }
         } else
-        for (int ks = wave; ks < p.ksteps; ks += 4) {
+        for (int ks = wave; ks < p.ksteps; ks += HEAD_NW) {
             half8 a = *(const half8 *)(xrow + 32 * ks);
 #pragma unroll
             for (int o = 0; o < OTG; o++)
@@ -445,13 +446,13 @@ __global__ __launch_bounds__(256) void az_head_kernel(HeadParams p) {
 #pragma unroll
         for (int o = 0; o < OTG; o++) *(f32x4 *)(part + ((wave * OTG + o) * 64 + lane) * 4) = acc[o];
         __syncthreads();
-        // 256 threads sum the 4 partials of OTG*64 float4 slots (= 512 slots: two per thread)
-        for (int s = tid; s < OTG * 64; s += 256) {
+        // the threads sum the HEAD_NW partials of OTG*64 float4 slots
+        for (int s = tid; s < OTG * 64; s += HEAD_NW * 64) {
             int o = s >> 6, ln = s & 63;
             if (og + o >= p.n_ot) continue;
             f32x4 v = *(f32x4 *)(part + ((0 * OTG + o) * 64 + ln) * 4);
 #pragma unroll
-            for (int w = 1; w < 4; w++) v += *(f32x4 *)(part + ((w * OTG + o) * 64 + ln) * 4);
+            for (int w = 1; w < HEAD_NW; w++) v += *(f32x4 *)(part + ((w * OTG + o) * 64 + ln) * 4);
             int col = 16 * (og + o) + (ln & 15);
             float bias = p.fc_b[col];
 #pragma unroll
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void az_head_kernel(HeadParams p) {
         __syncthreads();
     }
     // softmax over the first A logits, tanh of logit A: 16 lanes per board
-    const int brd = tid >> 4, sub = tid & 15;
+    const int brd = (tid >> 4) & 15, sub = tid & 15; // (threads 256.. repeat the work of 0..255 and store nothing)
     const float *lg = logits + brd * NP;
     float mx = -INFINITY;
     for (int o = sub; o < p.A; o += 16) mx = fmaxf(mx, lg[o]);
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256) void az_head_kernel(HeadParams p) {
     for (int o = sub; o < p.A; o += 16) sum += __expf(lg[o] - mx);
 #pragma unroll
     for (int off = 8; off; off >>= 1) sum += __shfl_xor(sum, off, 16);
-    if (b0 + brd < p.n_boards) {
+    if (tid < 256 && b0 + brd < p.n_boards) {
         float inv = 1.f / sum;
         float *out = p.priors + (size_t)(b0 + brd) * p.A;
         for (int o = sub; o < p.A; o += 16) out[o] = __expf(lg[o] - mx) * inv;
@@ -647,7 +648,7 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     }
     n->bpw_max = best;
     n->n_ot = (d.num_actions + 1 + 15) / 16;
-    n->lds_head = 4 * OTG * 64 * 16 + 16 * n->n_ot * 16 * 4;
+    n->lds_head = HEAD_NW * OTG * 64 * 16 + 16 * n->n_ot * 16 * 4;
     hipError_t s = hipSetDevice(d.device);
     if (s != hipSuccess) {
         g_net_err = std::string("hipSetDevice: ") + hipGetErrorString(s);
@@ -824,7 +825,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
             NCHK(n, hipFuncSetAttribute((const void *)az_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             head_attr[n->d.device & 15] = true;
         }
-        hipLaunchKernelGGL(az_head_kernel, dim3((n_boards + 15) / 16), dim3(256), n->lds_head, st, hp);
+        hipLaunchKernelGGL(az_head_kernel, dim3((n_boards + 15) / 16), dim3(HEAD_NW * 64), n->lds_head, st, hp);
     }
     NCHK(n, hipGetLastError());
     return AZ_OK;
