@@ -352,191 +352,6 @@ __device__ __forceinline__ void backup_path(const Pool &t, const Path<NP> &path,
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Kernel 1 (hot): consume network results, then MCTS.playout until the network is needed again.
-template <int GAME, int NP>
-__global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *__restrict__ priors,
-                                                         const float *__restrict__ values, float *__restrict__ obs_out) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= p.G) return;
-    int ph = rfl(p.phase[g]);
-    if (ph != PH_RUN && ph != PH_WAIT_LEAF && ph != PH_WAIT_ROOT) return;
-
-    const AzGeom &geom = p.geom;
-    SlotRegs sr;
-    slot_load(p, g, sr);
-    Pool t = pool_at(p, g, sr.half);
-    unsigned long long st_sims = 0, st_evals = 0, st_term = 0, st_depth = 0, st_children = 0, st_nodes = 0;
-    unsigned int fault = 0;
-    Path<NP> path;
-#pragma unroll
-    for (int i = 0; i < NP; i++) path.r[i] = 0;
-
-    // ---- 1. consume the outstanding request ----------------------------------------------------
-    if (ph == PH_WAIT_LEAF || ph == PH_WAIT_ROOT) {
-        const float *pri = priors + (size_t)g * p.A;
-        AzState ls;
-        uint32_t node;
-        int depth = 0;
-        if (ph == PH_WAIT_LEAF) {
-            ls.bb0 = rfl64(p.leaf_bb0[g]);
-            ls.bb1 = rfl64(p.leaf_bb1[g]);
-            ls.ply = rfl(p.leaf_ply[g]);
-            node = rflu(p.leaf_node[g]);
-            depth = rfl(p.depth[g]);
-#pragma unroll
-            for (int i = 0; i < NP; i++) path.r[i] = p.path[(size_t)g * p.pstride + i * 64 + lane];
-        } else {
-            ls = sr.rs;
-            node = sr.root;
-        }
-        int k[3], act[3], mine;
-        int n = enum_moves<GAME>(ls, geom, lane, k, act, mine);
-        uint32_t c0 = rflu(t.C0[node]);
-        bool fresh = (c0 == NONE32);
-        if (fresh) {
-            if (sr.alloc + (uint32_t)n > p.cap) {
-                fault |= AZ_FAULT_POOL_EXHAUSTED;
-                n = 0;
-                mine = 0;
-            }
-            c0 = sr.alloc;
-        }
-        double eta[3] = {0.0, 0.0, 0.0};
-        if (ph == PH_WAIT_ROOT) { // mcts.py:182-190
-            // injected draws (parity mode) or the Philox draws az_move_kernel staged with the request
-            const double *e = p.rng_mode == AZ_RNG_INJECTED
-                                  ? p.etas + ((size_t)sr.gid * p.max_plies + sr.rs.ply) * p.maxc
-                                  : p.eta_buf + (size_t)g * p.maxc;
-            for (int j = 0; j < mine; j++) eta[j] = e[k[j]];
-        }
-        for (int j = 0; j < mine; j++) {
-            float pf = pri[act[j]];
-            if (!(pf == pf)) fault |= AZ_FAULT_BAD_PRIOR;
-            double pv = (double)pf;
-            if (ph == PH_WAIT_ROOT) pv = p.one_minus_ratio * pv + 0.25 * eta[j]; // literal 0.25: mcts.py:189
-            uint32_t i = c0 + (uint32_t)k[j];
-            t.P[i] = pv;
-            if (fresh) { // mcts.py:63-64: Node(parent, prior)
-                t.N[i] = 0;
-                t.Q[i] = 0.0;
-                t.C0[i] = NONE32;
-                t.META[i] = (uint32_t)act[j];
-            }
-        }
-        if (fresh && n > 0) {
-            if (lane == 0) {
-                t.C0[node] = c0;
-                t.META[node] = (t.META[node] & 0xFFFFu) | ((uint32_t)n << 16);
-            }
-            sr.alloc += (uint32_t)n;
-            st_nodes += (unsigned long long)n;
-        }
-        if (ph == PH_WAIT_LEAF) { // mcts.py:152: node.update_recursive(-leaf_value)
-            float vf = values[g];
-            if (!(vf == vf)) fault |= AZ_FAULT_BAD_PRIOR;
-            backup_path<NP>(t, path, depth, -(double)vf, lane);
-            sr.sims++;
-            st_sims++;
-            st_depth += (unsigned long long)depth;
-        }
-        __threadfence_block();
-    }
-
-    // ---- 2. playouts until the network is needed again -------------------------------------------
-    int budget = p.max_sims_per_tick;
-    int next_phase = PH_RUN;
-    for (;;) {
-        if (__ballot(fault != 0)) { // faults are raised per lane: make the exit wave-uniform
-            next_phase = PH_IDLE;
-            break;
-        }
-        if (sr.sims >= p.S) { // the agent's move step runs in az_move_kernel
-            next_phase = PH_MOVE;
-            break;
-        }
-        if (budget-- <= 0) {
-            next_phase = PH_RUN;
-            break;
-        }
-        // ================= MCTS.playout (mcts.py:126-153) =================
-        AzState s = sr.rs;
-        uint32_t node = sr.root;
-        uint32_t np_ = rflu(t.N[node]);
-        uint32_t c0 = rflu(t.C0[node]);
-        int nc = c0 == NONE32 ? 0 : (int)(rflu(t.META[node]) >> 16);
-        int depth = 0, term = 0;
-        float ret0 = 0.f;
-        int mover = s.ply & 1;
-        path.set(lane, 0, node);
-        while (nc > 0 && !term) {
-            mover = s.ply & 1;
-            double val = -INFINITY;
-            uint32_t cn = 0, cc0 = NONE32, cmeta = 0;
-            if (lane < nc) {
-                uint32_t i = c0 + lane;
-                cn = t.N[i];
-                double q = t.Q[i], pp = t.P[i];
-                cc0 = t.C0[i];
-                cmeta = t.META[i];
-                val = q + ((p.c_puct * pp) * sqrt((double)np_)) / (double)(cn + 1); // mcts.py:78
-            }
-            double mx = wave_max(val);
-            unsigned long long eq = __ballot(val == mx);
-            int best = eq ? __ffsll(eq) - 1 : 0; // first maximum in child order (mcts.py:50)
-            if (!eq) fault |= AZ_FAULT_BAD_PRIOR;
-            st_children += (unsigned long long)nc;
-            node = c0 + (uint32_t)best;
-            np_ = rflu(__shfl(cn, best));
-            c0 = rflu(__shfl(cc0, best));
-            uint32_t meta = rflu(__shfl(cmeta, best));
-            nc = c0 == NONE32 ? 0 : (int)(meta >> 16);
-            term = az_apply<GAME>(s, geom, (int)(meta & 0xFFFFu), &ret0);
-            depth++;
-            path.set(lane, depth, node);
-        }
-        if (term) { // mcts.py:148-152: leaf_value = -player_return(mover); update_recursive(-leaf_value)
-            double x = mover == 0 ? (double)ret0 : -(double)ret0;
-            backup_path<NP>(t, path, depth, x, lane);
-            __threadfence_block();
-            sr.sims++;
-            st_sims++;
-            st_term++;
-            st_depth += (unsigned long long)depth;
-            continue;
-        }
-        // non-terminal leaf: ask the network (mcts.py:146)
-        write_obs<GAME>(p, s, obs_out + (size_t)g * p.obs_elems, lane);
-        st_evals++;
-        if (lane == 0) {
-            p.leaf_bb0[g] = s.bb0;
-            p.leaf_bb1[g] = s.bb1;
-            p.leaf_ply[g] = s.ply;
-            p.leaf_node[g] = node;
-            p.depth[g] = depth;
-        }
-#pragma unroll
-        for (int i = 0; i < NP; i++) p.path[(size_t)g * p.pstride + i * 64 + lane] = path.r[i];
-        next_phase = PH_WAIT_LEAF;
-        break;
-    }
-
-    // ---- 3. write the slot back ----------------------------------------------------------------
-    fault = wave_or(fault);
-    if (lane == 0) {
-        slot_store(p, g, sr, next_phase);
-        unsigned long long *st = p.stats + (size_t)g * ST_N;
-        st[ST_SIMS] += st_sims;
-        st[ST_EVALS] += st_evals;
-        st[ST_TERM] += st_term;
-        st[ST_DEPTH] += st_depth;
-        st[ST_CHILDREN] += st_children;
-        st[ST_NODES] += st_nodes;
-        if (fault) atomicOr(p.faults, fault);
-    }
-}
-
 // mcts.update_root(action) (mcts.py:192-203) + the pool bookkeeping it implies here.
 // `sel` = index of the chosen child among the root's children, or -1 for "fresh tree".
 __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, int lane, unsigned int &fault,
@@ -562,15 +377,13 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernel 2 (cold): AlphaZeroBot.step's tail + play_game_self's loop body for slots whose S playouts are
-// done, game turnover, and the root-evaluation request of the next search.
+// The cold path of a tick: AlphaZeroBot.step's tail + play_game_self's loop body for a slot whose S playouts are
+// done (phase PH_MOVE, set by the previous tick), game turnover, and the root-evaluation request of the next search.
+// Runs at the START of the slot's wave in az_advance_kernel and ends the wave's tick, so its registers never
+// overlap the playout loop's (it used to be a kernel of its own: one more launch gap and ~11 us of serial latency
+// per tick; now moving slots run beside the other slots' playouts).
 template <int GAME>
-__global__ __launch_bounds__(256) void az_move_kernel(Params p, float *__restrict__ obs_out) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= p.G) return;
-    int ph = rfl(p.phase[g]);
-    if (ph != PH_MOVE && ph != PH_NEED_ROOT) return;
+__device__ __forceinline__ void move_step(const Params &p, const int g, const int lane, int ph, float *__restrict__ obs_out) {
     const AzGeom &geom = p.geom;
     SlotRegs sr;
     slot_load(p, g, sr);
@@ -731,6 +544,195 @@ __global__ __launch_bounds__(256) void az_move_kernel(Params p, float *__restric
         st[ST_MOVES] += st_moves;
         st[ST_EVALS] += st_evals;
         st[ST_COMPACT] += st_compact;
+        if (fault) atomicOr(p.faults, fault);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The tick kernel.  Hot path: consume network results, then MCTS.playout until the network is needed again.
+template <int GAME, int NP>
+__global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *__restrict__ priors,
+                                                         const float *__restrict__ values, float *__restrict__ obs_out) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= p.G) return;
+    int ph = rfl(p.phase[g]);
+    if (ph == PH_MOVE || ph == PH_NEED_ROOT) { // the agent's move / the next search's root request: ends this slot's tick
+        move_step<GAME>(p, g, lane, ph, obs_out);
+        return;
+    }
+    if (ph != PH_RUN && ph != PH_WAIT_LEAF && ph != PH_WAIT_ROOT) return;
+
+    const AzGeom &geom = p.geom;
+    SlotRegs sr;
+    slot_load(p, g, sr);
+    Pool t = pool_at(p, g, sr.half);
+    unsigned long long st_sims = 0, st_evals = 0, st_term = 0, st_depth = 0, st_children = 0, st_nodes = 0;
+    unsigned int fault = 0;
+    Path<NP> path;
+#pragma unroll
+    for (int i = 0; i < NP; i++) path.r[i] = 0;
+
+    // ---- 1. consume the outstanding request ----------------------------------------------------
+    if (ph == PH_WAIT_LEAF || ph == PH_WAIT_ROOT) {
+        const float *pri = priors + (size_t)g * p.A;
+        AzState ls;
+        uint32_t node;
+        int depth = 0;
+        if (ph == PH_WAIT_LEAF) {
+            ls.bb0 = rfl64(p.leaf_bb0[g]);
+            ls.bb1 = rfl64(p.leaf_bb1[g]);
+            ls.ply = rfl(p.leaf_ply[g]);
+            node = rflu(p.leaf_node[g]);
+            depth = rfl(p.depth[g]);
+#pragma unroll
+            for (int i = 0; i < NP; i++) path.r[i] = p.path[(size_t)g * p.pstride + i * 64 + lane];
+        } else {
+            ls = sr.rs;
+            node = sr.root;
+        }
+        int k[3], act[3], mine;
+        int n = enum_moves<GAME>(ls, geom, lane, k, act, mine);
+        uint32_t c0 = rflu(t.C0[node]);
+        bool fresh = (c0 == NONE32);
+        if (fresh) {
+            if (sr.alloc + (uint32_t)n > p.cap) {
+                fault |= AZ_FAULT_POOL_EXHAUSTED;
+                n = 0;
+                mine = 0;
+            }
+            c0 = sr.alloc;
+        }
+        double eta[3] = {0.0, 0.0, 0.0};
+        if (ph == PH_WAIT_ROOT) { // mcts.py:182-190
+            // injected draws (parity mode) or the Philox draws move_step staged with the request
+            const double *e = p.rng_mode == AZ_RNG_INJECTED
+                                  ? p.etas + ((size_t)sr.gid * p.max_plies + sr.rs.ply) * p.maxc
+                                  : p.eta_buf + (size_t)g * p.maxc;
+            for (int j = 0; j < mine; j++) eta[j] = e[k[j]];
+        }
+        for (int j = 0; j < mine; j++) {
+            float pf = pri[act[j]];
+            if (!(pf == pf)) fault |= AZ_FAULT_BAD_PRIOR;
+            double pv = (double)pf;
+            if (ph == PH_WAIT_ROOT) pv = p.one_minus_ratio * pv + 0.25 * eta[j]; // literal 0.25: mcts.py:189
+            uint32_t i = c0 + (uint32_t)k[j];
+            t.P[i] = pv;
+            if (fresh) { // mcts.py:63-64: Node(parent, prior)
+                t.N[i] = 0;
+                t.Q[i] = 0.0;
+                t.C0[i] = NONE32;
+                t.META[i] = (uint32_t)act[j];
+            }
+        }
+        if (fresh && n > 0) {
+            if (lane == 0) {
+                t.C0[node] = c0;
+                t.META[node] = (t.META[node] & 0xFFFFu) | ((uint32_t)n << 16);
+            }
+            sr.alloc += (uint32_t)n;
+            st_nodes += (unsigned long long)n;
+        }
+        if (ph == PH_WAIT_LEAF) { // mcts.py:152: node.update_recursive(-leaf_value)
+            float vf = values[g];
+            if (!(vf == vf)) fault |= AZ_FAULT_BAD_PRIOR;
+            backup_path<NP>(t, path, depth, -(double)vf, lane);
+            sr.sims++;
+            st_sims++;
+            st_depth += (unsigned long long)depth;
+        }
+        __threadfence_block();
+    }
+
+    // ---- 2. playouts until the network is needed again -------------------------------------------
+    int budget = p.max_sims_per_tick;
+    int next_phase = PH_RUN;
+    for (;;) {
+        if (__ballot(fault != 0)) { // faults are raised per lane: make the exit wave-uniform
+            next_phase = PH_IDLE;
+            break;
+        }
+        if (sr.sims >= p.S) { // the agent's move step (move_step) opens this slot's next tick
+            next_phase = p.manual_moves ? PH_SEARCH_DONE : PH_MOVE;
+            break;
+        }
+        if (budget-- <= 0) {
+            next_phase = PH_RUN;
+            break;
+        }
+        // ================= MCTS.playout (mcts.py:126-153) =================
+        AzState s = sr.rs;
+        uint32_t node = sr.root;
+        uint32_t np_ = rflu(t.N[node]);
+        uint32_t c0 = rflu(t.C0[node]);
+        int nc = c0 == NONE32 ? 0 : (int)(rflu(t.META[node]) >> 16);
+        int depth = 0, term = 0;
+        float ret0 = 0.f;
+        int mover = s.ply & 1;
+        path.set(lane, 0, node);
+        while (nc > 0 && !term) {
+            mover = s.ply & 1;
+            double val = -INFINITY;
+            uint32_t cn = 0, cc0 = NONE32, cmeta = 0;
+            if (lane < nc) {
+                uint32_t i = c0 + lane;
+                cn = t.N[i];
+                double q = t.Q[i], pp = t.P[i];
+                cc0 = t.C0[i];
+                cmeta = t.META[i];
+                val = q + ((p.c_puct * pp) * sqrt((double)np_)) / (double)(cn + 1); // mcts.py:78
+            }
+            double mx = wave_max(val);
+            unsigned long long eq = __ballot(val == mx);
+            int best = eq ? __ffsll(eq) - 1 : 0; // first maximum in child order (mcts.py:50)
+            if (!eq) fault |= AZ_FAULT_BAD_PRIOR;
+            st_children += (unsigned long long)nc;
+            node = c0 + (uint32_t)best;
+            np_ = rflu(__shfl(cn, best));
+            c0 = rflu(__shfl(cc0, best));
+            uint32_t meta = rflu(__shfl(cmeta, best));
+            nc = c0 == NONE32 ? 0 : (int)(meta >> 16);
+            term = az_apply<GAME>(s, geom, (int)(meta & 0xFFFFu), &ret0);
+            depth++;
+            path.set(lane, depth, node);
+        }
+        if (term) { // mcts.py:148-152: leaf_value = -player_return(mover); update_recursive(-leaf_value)
+            double x = mover == 0 ? (double)ret0 : -(double)ret0;
+            backup_path<NP>(t, path, depth, x, lane);
+            __threadfence_block();
+            sr.sims++;
+            st_sims++;
+            st_term++;
+            st_depth += (unsigned long long)depth;
+            continue;
+        }
+        // non-terminal leaf: ask the network (mcts.py:146)
+        write_obs<GAME>(p, s, obs_out + (size_t)g * p.obs_elems, lane);
+        st_evals++;
+        if (lane == 0) {
+            p.leaf_bb0[g] = s.bb0;
+            p.leaf_bb1[g] = s.bb1;
+            p.leaf_ply[g] = s.ply;
+            p.leaf_node[g] = node;
+            p.depth[g] = depth;
+        }
+#pragma unroll
+        for (int i = 0; i < NP; i++) p.path[(size_t)g * p.pstride + i * 64 + lane] = path.r[i];
+        next_phase = PH_WAIT_LEAF;
+        break;
+    }
+
+    // ---- 3. write the slot back ----------------------------------------------------------------
+    fault = wave_or(fault);
+    if (lane == 0) {
+        slot_store(p, g, sr, next_phase);
+        unsigned long long *st = p.stats + (size_t)g * ST_N;
+        st[ST_SIMS] += st_sims;
+        st[ST_EVALS] += st_evals;
+        st[ST_TERM] += st_term;
+        st[ST_DEPTH] += st_depth;
+        st[ST_CHILDREN] += st_children;
+        st[ST_NODES] += st_nodes;
         if (fault) atomicOr(p.faults, fault);
     }
 }
@@ -1083,10 +1085,8 @@ extern "C" int az_engine_advance(az_engine *e, const float *priors, const float 
     }
     if (e->cfg.game == AZ_GAME_CONNECT_FOUR) {
         hipLaunchKernelGGL((az_advance_kernel<AZG_CONNECT_FOUR, 1>), grid, block, 0, st, e->p, priors, values, obs_out);
-        hipLaunchKernelGGL((az_move_kernel<AZG_CONNECT_FOUR>), grid, block, 0, st, e->p, obs_out);
     } else {
         hipLaunchKernelGGL((az_advance_kernel<AZG_BREAKTHROUGH, 3>), grid, block, 0, st, e->p, priors, values, obs_out);
-        hipLaunchKernelGGL((az_move_kernel<AZG_BREAKTHROUGH>), grid, block, 0, st, e->p, obs_out);
     }
     HIPCHK(e, hipGetLastError());
     e->ticks++;
