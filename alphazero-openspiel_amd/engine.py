@@ -307,7 +307,7 @@ def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_tick
     ticks = 0
     graph = None
     if use_graph:
-        # one tick = [az_advance_kernel, az_move_kernel, net.forward] replayed as a HIP graph
+        # one tick = [az_advance_kernel, net.forward] replayed as a HIP graph
         torch.cuda.synchronize(engine.device)
         side = torch.cuda.Stream(engine.device)
         side.wait_stream(torch.cuda.current_stream(engine.device))

@@ -259,8 +259,8 @@ def main():
     traffic_net = traffic_tree = None
     if (game.name, G, S, args.blocks, args.filters, args.net, args.weights) == ("connect_four", 4096, 400, 10, 50,
                                                                                 "fused", "random"):
-        traffic_net = 2 * (6709.5e3 + 11130.0e3) + 21738.8e3 + 128.0e3
-        traffic_tree = (9736.8e3 + 156.9e3) + (7032.8e3 + 17.5e3)
+        traffic_net = 2 * (6514.3e3 + 11125.5e3) + 21665.2e3 + 128.0e3
+        traffic_tree = 9797.3e3 + 7036.5e3
 
     if rank == 0:
         plies_per_game = moves_all / max(1.0, games_all)
@@ -288,7 +288,7 @@ def main():
                          "traffic": traffic_net, "traffic_unit": "bytes/launch (PMC, profiles/r1_hbm_traffic_pmc.txt)",
                          "flops_per_eval": f_eval, "ms_per_launch": 1e3 * t_net,
                          "batch_fill": evals_tick / G},
-            "roofline_tree": {"bound": "hbm", "kernel": "az_advance_kernel + az_move_kernel",
+            "roofline_tree": {"bound": "hbm", "kernel": "az_advance_kernel (playouts + move step)",
                               "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": tree_gbs / HBM_PEAK_GBS, "traffic": traffic_tree, "bytes_per_sim": b_sim,
                               "sims_per_launch": sims_tick, "ms_per_launch": 1e3 * t_tree},
