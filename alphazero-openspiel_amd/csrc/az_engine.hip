@@ -200,21 +200,17 @@ __device__ double np_sum_sparse(const PwPlan &pw, double v, int act, int nc) {
 
 // ------------------------------------------------------------------------------------------------
 struct Pool {
-    uint32_t *N, *C0, *META;
-    double *Q, *P;
+    AzNode *nd;
 };
 __device__ __forceinline__ Pool pool_at(const Params &p, int g, int half) {
     size_t base = ((size_t)g * 2 + half) * p.cap;
-    Pool q = {p.N + base, p.C0 + base, p.META + base, p.Q + base, p.P + base};
+    Pool q = {p.nodes + base};
     return q;
 }
 __device__ __forceinline__ void pool_init_root(const Pool &t, int lane) {
     if (lane == 0) {
-        t.N[0] = 0;
-        t.Q[0] = 0.0;
-        t.P[0] = 0.0;
-        t.C0[0] = NONE32;
-        t.META[0] = 0;
+        AzNode r = {0u, NONE32, 0u, 0u, 0.0, 0.0};
+        t.nd[0] = r;
     }
 }
 
@@ -264,11 +260,7 @@ template <int GAME> __device__ __forceinline__ void write_obs(const Params &p, c
 // Returns the number of live nodes.  Children stay contiguous and in ascending-action order.
 __device__ uint32_t compact_subtree(const Pool &a, const Pool &b, uint32_t root, int lane) {
     if (lane == 0) {
-        b.N[0] = a.N[root];
-        b.Q[0] = a.Q[root];
-        b.P[0] = a.P[root];
-        b.C0[0] = a.C0[root]; // still an OLD index until scanned
-        b.META[0] = a.META[root];
+        b.nd[0] = a.nd[root]; // C0 is still an OLD index until scanned
     }
     __threadfence_block();
     uint32_t s = 0, f = 1;
@@ -277,13 +269,13 @@ __device__ uint32_t compact_subtree(const Pool &a, const Pool &b, uint32_t root,
         uint32_t oc0 = NONE32;
         int nch = 0;
         if ((uint32_t)lane < cnt) {
-            oc0 = b.C0[s + lane];
-            nch = oc0 == NONE32 ? 0 : (int)(b.META[s + lane] >> 16);
+            oc0 = b.nd[s + lane].C0;
+            nch = oc0 == NONE32 ? 0 : (int)(b.nd[s + lane].META >> 16);
         }
         int incl = wave_incl_scan(nch, lane);
         int total = __shfl(incl, 63);
         uint32_t dst = f + (uint32_t)(incl - nch);
-        if (nch > 0) b.C0[s + lane] = dst;
+        if (nch > 0) b.nd[s + lane].C0 = dst;
         int mx = nch;
 #pragma unroll
         for (int off = 32; off; off >>= 1) {
@@ -293,11 +285,7 @@ __device__ uint32_t compact_subtree(const Pool &a, const Pool &b, uint32_t root,
         for (int k = 0; k < mx; k++)
             if (k < nch) {
                 uint32_t si = oc0 + k, di = dst + k;
-                b.N[di] = a.N[si];
-                b.Q[di] = a.Q[si];
-                b.P[di] = a.P[si];
-                b.C0[di] = a.C0[si];
-                b.META[di] = a.META[si];
+                b.nd[di] = a.nd[si];
             }
         __threadfence_block(); // the next chunk reads what this one wrote (same wave, global memory)
         f += (uint32_t)total;
@@ -344,10 +332,10 @@ __device__ __forceinline__ void backup_path(const Pool &t, const Path<NP> &path,
         if (d <= depth) {
             uint32_t nd = path.r[i];
             double xv = ((depth - d) & 1) ? -x : x;
-            uint32_t nn = t.N[nd];
-            double q = t.Q[nd];
-            t.Q[nd] = ((double)nn * q + xv) / (double)(nn + 1); // mcts.py:83
-            t.N[nd] = nn + 1;
+            uint32_t nn = t.nd[nd].N;
+            double q = t.nd[nd].Q;
+            t.nd[nd].Q = ((double)nn * q + xv) / (double)(nn + 1); // mcts.py:83
+            t.nd[nd].N = nn + 1;
         }
     }
 }
@@ -356,7 +344,7 @@ __device__ __forceinline__ void backup_path(const Pool &t, const Path<NP> &path,
 // `sel` = index of the chosen child among the root's children, or -1 for "fresh tree".
 __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, int lane, unsigned int &fault,
                        unsigned long long &st_compact) {
-    uint32_t c0 = rflu(t.C0[sr.root]);
+    uint32_t c0 = rflu(t.nd[sr.root].C0);
     if (sel < 0 || c0 == NONE32) { // root.is_leaf() or keep_search_tree=False: a new root Node
         sr.root = 0;
         sr.alloc = 1;
@@ -396,15 +384,15 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
             if (lane == 0) p.phase[g] = PH_SEARCH_DONE;
             return;
         }
-        uint32_t c0 = rflu(t.C0[sr.root]);
-        int nc = c0 == NONE32 ? 0 : (int)(rflu(t.META[sr.root]) >> 16);
+        uint32_t c0 = rflu(t.nd[sr.root].C0);
+        int nc = c0 == NONE32 ? 0 : (int)(rflu(t.nd[sr.root].META) >> 16);
         uint32_t cn = 0;
         int cact = 0;
         double cq = 0.0;
         if (lane < nc) {
-            cn = t.N[c0 + lane];
-            cq = t.Q[c0 + lane];
-            cact = (int)(t.META[c0 + lane] & 0xFFFFu);
+            cn = t.nd[c0 + lane].N;
+            cq = t.nd[c0 + lane].Q;
+            cact = (int)(t.nd[c0 + lane].META & 0xFFFFu);
         }
         long long tot = wave_sum_ll((long long)cn);
         if (nc == 0 || tot <= 0) fault |= AZ_FAULT_NO_VISITS;
@@ -419,23 +407,23 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         // value target (game_utils.py:168-194)
         double target = 0.0;
         if (p.backup == AZ_BACKUP_SOFT_Z) {
-            target = -t.Q[sr.root];
+            target = -t.nd[sr.root].Q;
         } else if (p.backup == AZ_BACKUP_A0C) {
             target = wave_max(lane < nc ? (cn > 0 ? cq : -99.0) : -INFINITY);
         } else if (p.backup == AZ_BACKUP_OFF_POLICY) { // A0GB: walk the most-visited line
-            uint32_t node = sr.root, nn = rflu(t.N[sr.root]);
+            uint32_t node = sr.root, nn = rflu(t.nd[sr.root].N);
             double value = 0.0, mult = 1.0;
             uint32_t kc0 = c0;
             int knc = nc;
             while (knc > 0) {
-                value = t.Q[node];
+                value = t.nd[node].Q;
                 double sc = -INFINITY;
                 uint32_t n2 = 0, c2 = NONE32, m2 = 0;
                 if (lane < knc) {
-                    n2 = t.N[kc0 + lane];
-                    c2 = t.C0[kc0 + lane];
-                    m2 = t.META[kc0 + lane];
-                    sc = n2 > 0 ? (double)n2 + t.P[kc0 + lane] : -99.0;
+                    n2 = t.nd[kc0 + lane].N;
+                    c2 = t.nd[kc0 + lane].C0;
+                    m2 = t.nd[kc0 + lane].META;
+                    sc = n2 > 0 ? (double)n2 + t.nd[kc0 + lane].P : -99.0;
                 }
                 double mx = wave_max(sc);
                 int best = __ffsll((unsigned long long)__ballot(sc == mx)) - 1;
@@ -446,7 +434,7 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
                 mult *= -1.0;
             }
             if (nn > 0) {
-                value = t.Q[node];
+                value = t.nd[node].Q;
                 mult *= -1.0;
             }
             target = value * mult;
@@ -593,7 +581,7 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *
         }
         int k[3], act[3], mine;
         int n = enum_moves<GAME>(ls, geom, lane, k, act, mine);
-        uint32_t c0 = rflu(t.C0[node]);
+        uint32_t c0 = rflu(t.nd[node].C0);
         bool fresh = (c0 == NONE32);
         if (fresh) {
             if (sr.alloc + (uint32_t)n > p.cap) {
@@ -617,18 +605,17 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *
             double pv = (double)pf;
             if (ph == PH_WAIT_ROOT) pv = p.one_minus_ratio * pv + 0.25 * eta[j]; // literal 0.25: mcts.py:189
             uint32_t i = c0 + (uint32_t)k[j];
-            t.P[i] = pv;
             if (fresh) { // mcts.py:63-64: Node(parent, prior)
-                t.N[i] = 0;
-                t.Q[i] = 0.0;
-                t.C0[i] = NONE32;
-                t.META[i] = (uint32_t)act[j];
+                AzNode nn = {0u, NONE32, (uint32_t)act[j], 0u, 0.0, pv};
+                t.nd[i] = nn;
+            } else {
+                t.nd[i].P = pv;
             }
         }
         if (fresh && n > 0) {
             if (lane == 0) {
-                t.C0[node] = c0;
-                t.META[node] = (t.META[node] & 0xFFFFu) | ((uint32_t)n << 16);
+                t.nd[node].C0 = c0;
+                t.nd[node].META = (t.nd[node].META & 0xFFFFu) | ((uint32_t)n << 16);
             }
             sr.alloc += (uint32_t)n;
             st_nodes += (unsigned long long)n;
@@ -663,9 +650,9 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *
         // ================= MCTS.playout (mcts.py:126-153) =================
         AzState s = sr.rs;
         uint32_t node = sr.root;
-        uint32_t np_ = rflu(t.N[node]);
-        uint32_t c0 = rflu(t.C0[node]);
-        int nc = c0 == NONE32 ? 0 : (int)(rflu(t.META[node]) >> 16);
+        uint32_t np_ = rflu(t.nd[node].N); // (N, C0, META share the node's first 16 bytes: one load)
+        uint32_t c0 = rflu(t.nd[node].C0);
+        int nc = c0 == NONE32 ? 0 : (int)(rflu(t.nd[node].META) >> 16);
         int depth = 0, term = 0;
         float ret0 = 0.f;
         int mover = s.ply & 1;
@@ -675,12 +662,11 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *
             double val = -INFINITY;
             uint32_t cn = 0, cc0 = NONE32, cmeta = 0;
             if (lane < nc) {
-                uint32_t i = c0 + lane;
-                cn = t.N[i];
-                double q = t.Q[i], pp = t.P[i];
-                cc0 = t.C0[i];
-                cmeta = t.META[i];
-                val = q + ((p.c_puct * pp) * sqrt((double)np_)) / (double)(cn + 1); // mcts.py:78
+                const AzNode c = t.nd[c0 + lane]; // the lane's child: two 16-byte loads
+                cn = c.N;
+                cc0 = c.C0;
+                cmeta = c.META;
+                val = c.Q + ((p.c_puct * c.P) * sqrt((double)np_)) / (double)(cn + 1); // mcts.py:78
             }
             double mx = wave_max(val);
             unsigned long long eq = __ballot(val == mx);
@@ -751,9 +737,9 @@ __global__ __launch_bounds__(256) void az_update_root_kernel(Params p, const int
     Pool t = pool_at(p, g, sr.half);
     unsigned int fault = 0;
     unsigned long long st_compact = 0;
-    uint32_t c0 = rflu(t.C0[sr.root]);
-    int nc = c0 == NONE32 ? 0 : (int)(rflu(t.META[sr.root]) >> 16);
-    int cact = lane < nc ? (int)(t.META[c0 + lane] & 0xFFFFu) : -1;
+    uint32_t c0 = rflu(t.nd[sr.root].C0);
+    int nc = c0 == NONE32 ? 0 : (int)(rflu(t.nd[sr.root].META) >> 16);
+    int cact = lane < nc ? (int)(t.nd[c0 + lane].META & 0xFFFFu) : -1;
     unsigned long long hit = __ballot(cact == action);
     int sel = (keep_subtree && hit) ? __ffsll(hit) - 1 : -1;
     float ret0 = 0.f;
@@ -784,11 +770,8 @@ __global__ void az_reset_kernel(Params p) {
     p.depth[g] = 0;
     p.leaf_node[g] = 0;
     size_t base = (size_t)g * 2 * p.cap;
-    p.N[base] = 0;
-    p.Q[base] = 0.0;
-    p.P[base] = 0.0;
-    p.C0[base] = NONE32;
-    p.META[base] = 0;
+    AzNode root0 = {0u, NONE32, 0u, 0u, 0.0, 0.0};
+    p.nodes[base] = root0;
     for (int i = 0; i < ST_N; i++) p.stats[(size_t)g * ST_N + i] = 0;
     if (g == 0) {
         *p.next_game = (unsigned long long)(p.n_games < p.G ? p.n_games : p.G);
@@ -922,7 +905,7 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     if (c.nodes_per_slot <= 0) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            int64_t fit = (int64_t)(free_b / 2 / ((size_t)c.n_slots * 2 * 28));
+            int64_t fit = (int64_t)(free_b / 2 / ((size_t)c.n_slots * 2 * sizeof(AzNode)));
             int64_t floor_cap = (int64_t)3 * p.need_per_move + 64;
             if (cap > fit) cap = fit > floor_cap ? fit : floor_cap;
         }
@@ -958,7 +941,7 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     size_t plies = (size_t)c.max_games * p.max_plies;
     int rc = AZ_OK;
 #define DA(ptr, n) if (rc == AZ_OK) rc = dalloc(e, &(ptr), (n))
-    DA(p.N, nodes); DA(p.C0, nodes); DA(p.META, nodes); DA(p.Q, nodes); DA(p.P, nodes);
+    DA(p.nodes, nodes);
     DA(p.phase, G); DA(p.gid, G); DA(p.ply, G); DA(p.sims, G); DA(p.which, G); DA(p.depth, G); DA(p.leaf_ply, G);
     DA(p.root, G); DA(p.alloc, G); DA(p.leaf_node, G); DA(p.path, G * p.pstride);
     DA(p.bb0, G); DA(p.bb1, G); DA(p.leaf_bb0, G); DA(p.leaf_bb1, G);
@@ -1246,10 +1229,12 @@ extern "C" int az_engine_read_root(az_engine *e, int32_t slot, int64_t *root_n, 
     HIPCHK(e, hipMemcpy(&root, e->p.root + slot, sizeof root, hipMemcpyDeviceToHost));
     size_t base = ((size_t)slot * 2 + half) * e->p.cap;
     double q = 0;
-    HIPCHK(e, hipMemcpy(&n, e->p.N + base + root, 4, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(&q, e->p.Q + base + root, 8, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(&c0, e->p.C0 + base + root, 4, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(&meta, e->p.META + base + root, 4, hipMemcpyDeviceToHost));
+    AzNode rn;
+    HIPCHK(e, hipMemcpy(&rn, e->p.nodes + base + root, sizeof rn, hipMemcpyDeviceToHost));
+    n = rn.N;
+    q = rn.Q;
+    c0 = rn.C0;
+    meta = rn.META;
     if (root_n) *root_n = n;
     if (root_q) *root_q = q;
     int nc = c0 == NONE32 ? 0 : (int)(meta >> 16);
@@ -1257,19 +1242,13 @@ extern "C" int az_engine_read_root(az_engine *e, int32_t slot, int64_t *root_n, 
         e->err = "corrupt root";
         return AZ_E_DEVICE;
     }
-    std::vector<uint32_t> N(nc), M(nc);
-    std::vector<double> Q(nc), P(nc);
-    if (nc) {
-        HIPCHK(e, hipMemcpy(N.data(), e->p.N + base + c0, 4 * nc, hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(M.data(), e->p.META + base + c0, 4 * nc, hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(Q.data(), e->p.Q + base + c0, 8 * nc, hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(P.data(), e->p.P + base + c0, 8 * nc, hipMemcpyDeviceToHost));
-    }
+    std::vector<AzNode> ch(nc);
+    if (nc) HIPCHK(e, hipMemcpy(ch.data(), e->p.nodes + base + c0, sizeof(AzNode) * nc, hipMemcpyDeviceToHost));
     for (int i = 0; i < nc; i++) {
-        if (actions) actions[i] = (int32_t)(M[i] & 0xFFFFu);
-        if (child_n) child_n[i] = N[i];
-        if (child_q) child_q[i] = Q[i];
-        if (child_p) child_p[i] = P[i];
+        if (actions) actions[i] = (int32_t)(ch[i].META & 0xFFFFu);
+        if (child_n) child_n[i] = ch[i].N;
+        if (child_q) child_q[i] = ch[i].Q;
+        if (child_p) child_p[i] = ch[i].P;
     }
     return nc;
 }
@@ -1289,13 +1268,17 @@ extern "C" int64_t az_engine_read_tree(az_engine *e, int32_t slot, int64_t max_n
         return AZ_E_DEVICE;
     }
     size_t base = ((size_t)slot * 2 + half) * e->p.cap;
+    std::vector<AzNode> nd_all(alloc);
+    HIPCHK(e, hipMemcpy(nd_all.data(), e->p.nodes + base, sizeof(AzNode) * (size_t)alloc, hipMemcpyDeviceToHost));
     std::vector<uint32_t> N(alloc), C0(alloc), M(alloc);
     std::vector<double> Q(alloc), P(alloc);
-    HIPCHK(e, hipMemcpy(N.data(), e->p.N + base, 4 * (size_t)alloc, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(C0.data(), e->p.C0 + base, 4 * (size_t)alloc, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(M.data(), e->p.META + base, 4 * (size_t)alloc, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(Q.data(), e->p.Q + base, 8 * (size_t)alloc, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(P.data(), e->p.P + base, 8 * (size_t)alloc, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < alloc; i++) {
+        N[i] = nd_all[i].N;
+        C0[i] = nd_all[i].C0;
+        M[i] = nd_all[i].META;
+        Q[i] = nd_all[i].Q;
+        P[i] = nd_all[i].P;
+    }
     std::vector<uint32_t> order;  // BFS queue of pool indices
     std::vector<int32_t> par;
     order.push_back(root);

@@ -14,6 +14,16 @@
 enum { PH_IDLE = 0, PH_RUN = 1, PH_MOVE = 2, PH_WAIT_ROOT = 3, PH_WAIT_LEAF = 4, PH_SEARCH_DONE = 5, PH_NEED_ROOT = 6 };
 enum { ST_MOVES = 0, ST_SIMS, ST_EVALS, ST_TERM, ST_DEPTH, ST_CHILDREN, ST_NODES, ST_COMPACT, ST_N };
 
+// One search-tree node (mcts.py:10-20 Node: N, Q, P, children).  32 bytes, so a block of sibling nodes is one
+// contiguous run and a lane fetches its child with two 16-byte loads.
+struct __attribute__((aligned(32))) AzNode {
+    uint32_t N;    // visit count
+    uint32_t C0;   // index of the first child in the slot's pool half (NONE32 = leaf)
+    uint32_t META; // action leading here | n_children << 16
+    uint32_t pad;
+    double Q, P;
+};
+
 struct PwPlan { // numpy pairwise-sum recursion for a length-A vector, flattened (see np_sum_sparse)
     int n_blocks;
     int lo[16], len[16];
@@ -32,9 +42,8 @@ struct Params {
     long long n_games, max_games;
     AzState start;
     PwPlan pw;
-    // node pools
-    uint32_t *N, *C0, *META;
-    double *Q, *P;
+    // node pools (array of structures: a child block is one contiguous run of 32-byte nodes)
+    AzNode *nodes;
     // per slot
     int *phase, *gid, *ply, *sims, *which, *depth, *leaf_ply;
     uint32_t *root, *alloc, *leaf_node, *path;
