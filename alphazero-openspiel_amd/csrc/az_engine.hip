@@ -215,13 +215,23 @@ __device__ __forceinline__ void pool_init_root(const Pool &t, int lane) {
 }
 
 template <int NP> struct Path { // depth d lives in lane d&63, register d>>6
-    uint32_t r[NP];
-    __device__ __forceinline__ void set(int lane, int d, uint32_t node) {
+    uint32_t r[NP];  // node index
+    uint32_t pn[NP]; // the node's N and Q as last read or written by this wave: the backup needs no second read
+    double pq[NP];
+    __device__ __forceinline__ void set(int lane, int d, uint32_t node, uint32_t n, double q) {
 #pragma unroll
         for (int i = 0; i < NP; i++)
-            if ((d >> 6) == i && lane == (d & 63)) r[i] = node;
+            if ((d >> 6) == i && lane == (d & 63)) {
+                r[i] = node;
+                pn[i] = n;
+                pq[i] = q;
+            }
     }
 };
+__device__ __forceinline__ double readlane_d(double v, int src) { // src wave-uniform
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
 
 // Enumerate the legal actions of `s` in ascending order, one wave.  For each of this lane's (<=3)
 // moves: slot index k (position in the ascending list) and action id.  Returns total count.
@@ -323,19 +333,22 @@ __device__ __forceinline__ void slot_store(const Params &p, int g, const SlotReg
     p.alloc[g] = r.alloc;
 }
 
-// mcts.py:82-89 update_recursive along the recorded path: node at depth d gets x * (-1)^(depth-d)
+// mcts.py:82-89 update_recursive along the recorded path: node at depth d gets x * (-1)^(depth-d).  N and Q of every
+// path node are already in the lane's registers (read on the way down, or loaded with the slot), so this only stores.
 template <int NP>
-__device__ __forceinline__ void backup_path(const Pool &t, const Path<NP> &path, int depth, double x, int lane) {
+__device__ __forceinline__ void backup_path(const Pool &t, Path<NP> &path, int depth, double x, int lane) {
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         int d = i * 64 + lane;
         if (d <= depth) {
             uint32_t nd = path.r[i];
             double xv = ((depth - d) & 1) ? -x : x;
-            uint32_t nn = t.nd[nd].N;
-            double q = t.nd[nd].Q;
-            t.nd[nd].Q = ((double)nn * q + xv) / (double)(nn + 1); // mcts.py:83
+            uint32_t nn = path.pn[i];
+            double q = ((double)nn * path.pq[i] + xv) / (double)(nn + 1); // mcts.py:83
+            t.nd[nd].Q = q;
             t.nd[nd].N = nn + 1;
+            path.pq[i] = q;
+            path.pn[i] = nn + 1;
         }
     }
 }
@@ -371,10 +384,9 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, i
 // overlap the playout loop's (it used to be a kernel of its own: one more launch gap and ~11 us of serial latency
 // per tick; now moving slots run beside the other slots' playouts).
 template <int GAME>
-__device__ __forceinline__ void move_step(const Params &p, const int g, const int lane, int ph, float *__restrict__ obs_out) {
+__device__ __forceinline__ void move_step(const Params &p, const int g, const int lane, int ph, SlotRegs sr,
+                                          float *__restrict__ obs_out) {
     const AzGeom &geom = p.geom;
-    SlotRegs sr;
-    slot_load(p, g, sr);
     Pool t = pool_at(p, g, sr.half);
     unsigned long long st_moves = 0, st_evals = 0, st_compact = 0;
     unsigned int fault = 0;
@@ -544,52 +556,85 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= p.G) return;
-    int ph = rfl(p.phase[g]);
+    // ---- 0. everything that is addressed by the slot index alone: ONE memory round trip ------------------------
+    // (the kernel is a chain of dependent reads - PMC: waves parked in s_waitcnt 63 % of their life - so its duration
+    //  is the number of round trips on the longest chain)
+    const int ph_raw = p.phase[g];
+    SlotRegs sr;
+    const int lf_ply_raw = p.leaf_ply[g], lf_depth_raw = p.depth[g];
+    const uint32_t lf_node_raw = p.leaf_node[g];
+    const uint64_t lf_bb0_raw = p.leaf_bb0[g], lf_bb1_raw = p.leaf_bb1[g];
+    uint32_t path_raw[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) path_raw[i] = p.path[(size_t)g * p.pstride + i * 64 + lane];
+    const float value_raw = values ? values[g] : 0.f;
+    slot_load(p, g, sr);
+    const int ph = rfl(ph_raw);
     if (ph == PH_MOVE || ph == PH_NEED_ROOT) { // the agent's move / the next search's root request: ends this slot's tick
-        move_step<GAME>(p, g, lane, ph, obs_out);
+        move_step<GAME>(p, g, lane, ph, sr, obs_out);
         return;
     }
     if (ph != PH_RUN && ph != PH_WAIT_LEAF && ph != PH_WAIT_ROOT) return;
 
     const AzGeom &geom = p.geom;
-    SlotRegs sr;
-    slot_load(p, g, sr);
     Pool t = pool_at(p, g, sr.half);
     unsigned long long st_sims = 0, st_evals = 0, st_term = 0, st_depth = 0, st_children = 0, st_nodes = 0;
     unsigned int fault = 0;
     Path<NP> path;
 #pragma unroll
-    for (int i = 0; i < NP; i++) path.r[i] = 0;
+    for (int i = 0; i < NP; i++) {
+        path.r[i] = 0;
+        path.pn[i] = 0;
+        path.pq[i] = 0.0;
+    }
 
-    // ---- 1. consume the outstanding request ----------------------------------------------------
+    // ---- 1. second round trip: the root node, and (request outstanding) the nodes of the recorded path ----------
+    const AzNode rootn = t.nd[sr.root]; // same address in every lane
+    uint32_t root_n = rflu(rootn.N), root_c0 = rflu(rootn.C0), root_meta = rflu(rootn.META);
+    if (lane == 0) { // depth 0 of every path
+        path.r[0] = sr.root;
+        path.pn[0] = rootn.N;
+        path.pq[0] = rootn.Q;
+    }
     if (ph == PH_WAIT_LEAF || ph == PH_WAIT_ROOT) {
         const float *pri = priors + (size_t)g * p.A;
         AzState ls;
-        uint32_t node;
+        uint32_t node, node_act;
         int depth = 0;
+        bool fresh;
+        uint32_t c0;
         if (ph == PH_WAIT_LEAF) {
-            ls.bb0 = rfl64(p.leaf_bb0[g]);
-            ls.bb1 = rfl64(p.leaf_bb1[g]);
-            ls.ply = rfl(p.leaf_ply[g]);
-            node = rflu(p.leaf_node[g]);
-            depth = rfl(p.depth[g]);
+            ls.bb0 = rfl64(lf_bb0_raw);
+            ls.bb1 = rfl64(lf_bb1_raw);
+            ls.ply = rfl(lf_ply_raw);
+            node = rflu(lf_node_raw);
+            const int dm = rfl(lf_depth_raw); // depth | action leading to the leaf << 16
+            depth = dm & 0xFFFF;
+            node_act = (uint32_t)dm >> 16;
 #pragma unroll
-            for (int i = 0; i < NP; i++) path.r[i] = p.path[(size_t)g * p.pstride + i * 64 + lane];
+            for (int i = 0; i < NP; i++) {
+                path.r[i] = path_raw[i];
+                if (i * 64 + lane <= depth) { // N and Q of the path nodes, BEFORE anything of this tick is stored
+                    path.pn[i] = t.nd[path_raw[i]].N;
+                    path.pq[i] = t.nd[path_raw[i]].Q;
+                }
+            }
+            fresh = true; // a request is only ever issued for an unexpanded node (nc == 0 below)
+            c0 = sr.alloc;
         } else {
             ls = sr.rs;
             node = sr.root;
+            node_act = root_meta & 0xFFFFu;
+            c0 = root_c0;
+            fresh = (c0 == NONE32);
+            if (fresh) c0 = sr.alloc;
         }
         int k[3], act[3], mine;
         int n = enum_moves<GAME>(ls, geom, lane, k, act, mine);
-        uint32_t c0 = rflu(t.nd[node].C0);
-        bool fresh = (c0 == NONE32);
-        if (fresh) {
-            if (sr.alloc + (uint32_t)n > p.cap) {
-                fault |= AZ_FAULT_POOL_EXHAUSTED;
-                n = 0;
-                mine = 0;
-            }
-            c0 = sr.alloc;
+        if (fresh && sr.alloc + (uint32_t)n > p.cap) {
+            fault |= AZ_FAULT_POOL_EXHAUSTED;
+            n = 0;
+            mine = 0;
         }
         double eta[3] = {0.0, 0.0, 0.0};
         if (ph == PH_WAIT_ROOT) { // mcts.py:182-190
@@ -615,20 +660,25 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *
         if (fresh && n > 0) {
             if (lane == 0) {
                 t.nd[node].C0 = c0;
-                t.nd[node].META = (t.nd[node].META & 0xFFFFu) | ((uint32_t)n << 16);
+                t.nd[node].META = node_act | ((uint32_t)n << 16);
+            }
+            if (node == sr.root) { // the root itself was the unexpanded node (root request, or a depth-0 leaf request)
+                root_c0 = c0;
+                root_meta = node_act | ((uint32_t)n << 16);
             }
             sr.alloc += (uint32_t)n;
             st_nodes += (unsigned long long)n;
         }
         if (ph == PH_WAIT_LEAF) { // mcts.py:152: node.update_recursive(-leaf_value)
-            float vf = values[g];
+            float vf = value_raw;
             if (!(vf == vf)) fault |= AZ_FAULT_BAD_PRIOR;
             backup_path<NP>(t, path, depth, -(double)vf, lane);
+            root_n++;
             sr.sims++;
             st_sims++;
             st_depth += (unsigned long long)depth;
         }
-        __threadfence_block();
+        __threadfence_block(); // this wave's stores before its next reads of the same nodes
     }
 
     // ---- 2. playouts until the network is needed again -------------------------------------------
@@ -648,24 +698,27 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *
             break;
         }
         // ================= MCTS.playout (mcts.py:126-153) =================
+        // The root's N / first child / child count are carried in registers from the load above (N grows by one per
+        // playout); lane 0 of the path carries its N and Q.
         AzState s = sr.rs;
         uint32_t node = sr.root;
-        uint32_t np_ = rflu(t.nd[node].N); // (N, C0, META share the node's first 16 bytes: one load)
-        uint32_t c0 = rflu(t.nd[node].C0);
-        int nc = c0 == NONE32 ? 0 : (int)(rflu(t.nd[node].META) >> 16);
+        uint32_t np_ = root_n;
+        uint32_t c0 = root_c0;
+        uint32_t meta = root_meta;
+        int nc = c0 == NONE32 ? 0 : (int)(meta >> 16);
         int depth = 0, term = 0;
         float ret0 = 0.f;
         int mover = s.ply & 1;
-        path.set(lane, 0, node);
         while (nc > 0 && !term) {
             mover = s.ply & 1;
-            double val = -INFINITY;
+            double val = -INFINITY, cq = 0.0;
             uint32_t cn = 0, cc0 = NONE32, cmeta = 0;
             if (lane < nc) {
                 const AzNode c = t.nd[c0 + lane]; // the lane's child: two 16-byte loads
                 cn = c.N;
                 cc0 = c.C0;
                 cmeta = c.META;
+                cq = c.Q;
                 val = c.Q + ((p.c_puct * c.P) * sqrt((double)np_)) / (double)(cn + 1); // mcts.py:78
             }
             double mx = wave_max(val);
@@ -674,18 +727,20 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *
             if (!eq) fault |= AZ_FAULT_BAD_PRIOR;
             st_children += (unsigned long long)nc;
             node = c0 + (uint32_t)best;
-            np_ = rflu(__shfl(cn, best));
-            c0 = rflu(__shfl(cc0, best));
-            uint32_t meta = rflu(__shfl(cmeta, best));
+            np_ = (uint32_t)__builtin_amdgcn_readlane((int)cn, best);
+            c0 = (uint32_t)__builtin_amdgcn_readlane((int)cc0, best);
+            meta = (uint32_t)__builtin_amdgcn_readlane((int)cmeta, best);
+            const double qsel = readlane_d(cq, best);
             nc = c0 == NONE32 ? 0 : (int)(meta >> 16);
             term = az_apply<GAME>(s, geom, (int)(meta & 0xFFFFu), &ret0);
             depth++;
-            path.set(lane, depth, node);
+            path.set(lane, depth, node, np_, qsel);
         }
         if (term) { // mcts.py:148-152: leaf_value = -player_return(mover); update_recursive(-leaf_value)
             double x = mover == 0 ? (double)ret0 : -(double)ret0;
             backup_path<NP>(t, path, depth, x, lane);
             __threadfence_block();
+            root_n++;
             sr.sims++;
             st_sims++;
             st_term++;
@@ -700,7 +755,7 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *
             p.leaf_bb1[g] = s.bb1;
             p.leaf_ply[g] = s.ply;
             p.leaf_node[g] = node;
-            p.depth[g] = depth;
+            p.depth[g] = depth | (int)((meta & 0xFFFFu) << 16); // + the action leading to the leaf (its META low half)
         }
 #pragma unroll
         for (int i = 0; i < NP; i++) p.path[(size_t)g * p.pstride + i * 64 + lane] = path.r[i];
@@ -1214,6 +1269,7 @@ extern "C" int az_engine_read_slot(az_engine *e, int32_t slot, az_slot_info *o) 
     RD(o->root, e->p.root); RD(o->alloc, e->p.alloc); RD(o->bb[0], e->p.bb0); RD(o->bb[1], e->p.bb1);
     RD(o->leaf_bb[0], e->p.leaf_bb0); RD(o->leaf_bb[1], e->p.leaf_bb1); RD(o->leaf_ply, e->p.leaf_ply);
     RD(o->depth, e->p.depth);
+    o->depth &= 0xFFFF; // (the high half carries the action that leads to the requested leaf)
 #undef RD
     return AZ_OK;
 }
