@@ -18,7 +18,7 @@ class AzConfig(C.Structure):
                 ("n_slots", C.c_int32), ("n_playouts", C.c_int32), ("use_dirichlet", C.c_int32),
                 ("keep_search_tree", C.c_int32), ("backup", C.c_int32), ("rng_mode", C.c_int32),
                 ("max_sims_per_tick", C.c_int32), ("device", C.c_int32), ("manual_moves", C.c_int32),
-                ("reserved0", C.c_int32), ("nodes_per_slot", C.c_int64), ("max_games", C.c_int64),
+                ("chain_window_us", C.c_int32), ("nodes_per_slot", C.c_int64), ("max_games", C.c_int64),
                 ("c_puct", C.c_double), ("dirichlet_ratio", C.c_double), ("dirichlet_alpha", C.c_double),
                 ("temperature", C.c_double), ("seed", C.c_uint64)]
 

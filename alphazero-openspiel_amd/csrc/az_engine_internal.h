@@ -35,7 +35,7 @@ struct Params {
     // geometry / config
     AzGeom geom;
     int game, A, maxc, max_plies, obs_elems, pstride;
-    int G, S, use_dirichlet, keep_tree, backup, rng_mode, max_sims_per_tick, manual_moves;
+    int G, S, use_dirichlet, keep_tree, backup, rng_mode, max_sims_per_tick, manual_moves, chain_clocks;
     uint32_t cap, need_per_move;
     double c_puct, one_minus_ratio, alpha, inv_temp;
     uint64_t seed;

@@ -34,7 +34,7 @@ class SelfPlayEngine:
 
     def __init__(self, game_name, n_slots, n_playouts=100, c_puct=2.5, temperature=1.0, dirichlet_ratio=0.25,
                  use_dirichlet=True, keep_search_tree=True, backup="on-policy", max_games=None, device=0,
-                 rng="philox", seed=0, nodes_per_slot=0, max_sims_per_tick=0, manual_moves=False,
+                 rng="philox", seed=0, nodes_per_slot=0, max_sims_per_tick=0, chain_window_us=0, manual_moves=False,
                  dirichlet_alpha=0.3):
         self.lib = _lib.load()
         self.game = Game(game_name) if isinstance(game_name, str) else game_name
@@ -52,6 +52,7 @@ class SelfPlayEngine:
         cfg.backup = _lib.BACKUPS[backup]
         cfg.rng_mode = {"philox": _lib.RNG_PHILOX, "injected": _lib.RNG_INJECTED}[rng]
         cfg.max_sims_per_tick = int(max_sims_per_tick)
+        cfg.chain_window_us = int(chain_window_us)
         cfg.device = self.device_index
         cfg.manual_moves = int(bool(manual_moves))
         cfg.nodes_per_slot = int(nodes_per_slot)

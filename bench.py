@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--check-every", type=int, default=32)
     ap.add_argument("--nodes-per-slot", type=int, default=0, help="node-pool capacity per slot (0 = engine default)")
     ap.add_argument("--max-sims-per-tick", type=int, default=0, help="NN-free playouts a slot may chain per tick (0 = default)")
+    ap.add_argument("--chain-window-us", type=int, default=0, help="chained playouts only start this early in a launch (0 = default, <0 = off)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
@@ -156,7 +157,8 @@ def main():
 
     n_total = (Wm + K + 2) * G
     eng = E.SelfPlayEngine(game, G, n_playouts=S, max_games=n_total, device=device, seed=args.seed + 7919 * rank,
-                           nodes_per_slot=args.nodes_per_slot, max_sims_per_tick=args.max_sims_per_tick)
+                           nodes_per_slot=args.nodes_per_slot, max_sims_per_tick=args.max_sims_per_tick,
+                           chain_window_us=args.chain_window_us)
     eng.reset(n_total)
     obs, pri, val = eng.alloc_io()
 
