@@ -605,7 +605,7 @@ static TowerGeom tower_geom(int bpw, int waves, int H, int W) {
     g.waves = waves;
     int act = g.waves * wave_act;
     // 32 KiB weight chunks (half the barriers) when LDS allows; not with 8 waves: the longer unrolled body spills there
-    g.ck = (act + 6144 + 2 * 8 * 4096 <= 160 * 1024 && g.waves == 4) ? 8 : 4; // 32 KiB chunks when LDS/registers allow
+    g.ck = (act + 6144 + 2 * 8 * 4096 <= 160 * 1024) ? 8 : 4; // 32 KiB chunks (half the barriers) when LDS allows
     g.off_epi = 2 * g.ck * 4096;
     g.off_act = g.off_epi + 2048 + 8 * 64 * 8; // epilogue ring (2 KiB) + trash slots (8 B per thread, up to 512 threads)
     g.lds = g.off_act + act;
@@ -739,7 +739,7 @@ template <int NT, int CK, int WAVES> static hipError_t launch_tower(const az_net
 }
 template <int NT> static hipError_t launch_tower_ck(const az_net *n, const TowerParams &tp, int grid, const TowerGeom &g, hipStream_t st) {
     if constexpr (NT <= 3) {
-        if (g.waves == 8) return launch_tower<NT, 4, 8>(n, tp, grid, g.lds, st);
+        if (g.waves == 8) return g.ck == 8 ? launch_tower<NT, 8, 8>(n, tp, grid, g.lds, st) : launch_tower<NT, 4, 8>(n, tp, grid, g.lds, st);
     }
     return g.ck == 8 ? launch_tower<NT, 8, 4>(n, tp, grid, g.lds, st) : launch_tower<NT, 4, 4>(n, tp, grid, g.lds, st);
 }
