@@ -125,10 +125,20 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
 // 2 boards either way.  Wider boards keep the generic packing (n = 16*nt + l15 over positions, 2-way conflicts).
 // RP1: row-pair tiles with one board per wave: column tile nt sits exactly nt * 256 bytes after tile 0, so a B-fragment
 // address is one precomputed register per k-step plus an immediate.
-template <int NT, int CK, int WAVES, bool RP1>
+// R3: rows of output-channel tile 3 (channels 48..63) that are stored.  With <= 50 filters only 2 of its 16 rows are real:
+// the weight stream then carries, per k-step, three full fragments + 4 x (2 rows + 1 zero row) x 16 B = 3264 B instead
+// of 4096 B (-20 % LDS-DMA traffic, the most expensive ingredient of the k-loop); lanes of the missing rows read the
+// zero row (same address: a broadcast).  R3 = 16: plain 4 KiB records.
+template <int R3> struct WRec {
+    static constexpr int ROWS = R3 < 16 ? R3 + 1 : 16;   // stored rows per lane group (incl. the zero row)
+    static constexpr int BYTES = 3 * 1024 + 4 * ROWS * 16; // one k-step of weights
+};
+template <int NT, int CK, int WAVES, bool RP1, int R3>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int CHUNK_B = CK * 4 * 64 * 16;
+    constexpr int REC = WRec<R3>::BYTES;
+    constexpr int CHUNK_B = CK * REC;        // bytes of one chunk in the stream
+    constexpr int CHUNK_S = CK * 4 * 64 * 16; // stride of the two chunk buffers in LDS (the host's layout)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l15 = lane & 15;
     const int plane_b = p.rcells * OCT_B, region_b = N_OCT * plane_b;
@@ -223,21 +233,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
     // ---- weight stream: chunk c -> buffer c&1, by LDS-DMA (global_load_lds, 16 B/lane).  Chunk 0 = conv 0 (4 k-steps,
     // 16 KiB), chunk c >= 1 = CK k-steps of the 16-k-step convs that follow, contiguous in the device buffer.
     constexpr int PARTS = AZ_NET_KSTEPS / CK;
-    constexpr int C0_B = AZ_NET_K0STEPS * 4 * 64 * 16;
+    constexpr int C0_B = AZ_NET_K0STEPS * REC;
     static_assert(CK % 2 == 0 && AZ_NET_K0STEPS % 2 == 0, "fragment buffer parity relies on an even chunk length");
     static_assert(CK * 4 * 1024 <= 65536, "A-fragment offsets (relative to the chunk base) must fit the ds offset field");
-    static_assert(C0_B <= CHUNK_B && C0_B % (WAVES * 1024) == 0 && CHUNK_B % (WAVES * 1024) == 0, "DMA pieces are one KiB per wave");
+    static_assert(C0_B <= CHUNK_B && REC % 16 == 0 && ((CHUNK_B + 1023) & ~1023) <= CHUNK_S, "chunk must fit its LDS buffer");
     const int n_chunks = 1 + (p.n_convs - 1) * PARTS;
     auto issue_bytes = [&](const unsigned char *src, unsigned char *dst, auto bytes_c) {
+        constexpr int NPIECES = (decltype(bytes_c)::value + 1023) / 1024; // the last piece may run past the chunk: the
+                                                                          // stream is padded, the LDS buffer has the room
 #pragma unroll
-        for (int i = 0; i < decltype(bytes_c)::value / (WAVES * 64 * 16); i++) {
+        for (int i = 0; i < (NPIECES + WAVES - 1) / WAVES; i++) {
             int piece = i * WAVES + wave; // one KiB per wave-instruction, lane-linear
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
+            if (piece < NPIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
         }
     };
     auto issue_chunk = [&](int c) { // c >= 1
-        issue_bytes((const unsigned char *)p.conv_w + C0_B + (size_t)(c - 1) * CHUNK_B, lds + (c & 1) * CHUNK_B,
+        issue_bytes((const unsigned char *)p.conv_w + C0_B + (size_t)(c - 1) * CHUNK_B, lds + (c & 1) * CHUNK_S,
                     std::integral_constant<int, CHUNK_B>{});
     };
     issue_bytes((const unsigned char *)p.conv_w, lds, std::integral_constant<int, C0_B>{});
@@ -276,7 +289,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             //   wait(all of k-step ksl) ; for each read of k-step ksl+1: {ds_read ; MFMA of ksl} ; remaining MFMAs
             // so a read has most of an MFMA block (16 cycles per MFMA) to land before the next wait.  All loop indices
             // are compile-time (static_for), so fragment offsets sit in the instructions' offset fields.
-            const unsigned wbl = lds_base + (chunk & 1) * CHUNK_B + lane * 16;
+            const unsigned wbl = lds_base + (chunk & 1) * CHUNK_S + lane * 16;
+            // tile 3: lane (q, l15) reads stored row min(l15, ROWS - 1) of its k-group (the last stored row is zero)
+            const unsigned wbl3 = R3 == 16 ? wbl
+                                           : lds_base + (chunk & 1) * CHUNK_S +
+                                                 (q * WRec<R3>::ROWS + (l15 < WRec<R3>::ROWS - 1 ? l15 : WRec<R3>::ROWS - 1)) * 16;
             // B fragment of column tile nt in k-step ks (ks compile-time)
             auto read_b = [&](half8 &dst, auto ks_c, auto nt_c) {
                 constexpr int ks = decltype(ks_c)::value, nt = decltype(nt_c)::value;
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             // B_nt) are outstanding: counted s_waitcnt instead of lgkmcnt(0).
             static_for<4>([&](auto mt_c) {
                 constexpr int mt = decltype(mt_c)::value;
-                READ_A(a[0][mt], wbl, mt * 1024);
+                READ_A(a[0][mt], mt < 3 ? wbl : wbl3, mt * 1024);
             });
             if constexpr (part == 0) // later chunks of a conv had their B fragments fetched before the barrier
                 static_for<NT>([&](auto nt_c) { read_b(b[0][decltype(nt_c)::value], std::integral_constant<int, 0>{}, nt_c); });
@@ -327,7 +344,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                     }
                     if constexpr (j < n_next) { // one read of the next k-step per MFMA, in the same order
                         constexpr int r = more_here ? j : j + 4; // B-only prefetch skips the A slots
-                        if constexpr (r < 4) READ_A(a[nxt][r], wbl, ((ksl + 1) * 4 + r) * 1024);
+                        if constexpr (r < 4) READ_A(a[nxt][r], r < 3 ? wbl : wbl3, (ksl + 1) * REC + r * 1024);
                         else read_b(b[nxt][r - 4], std::integral_constant<int, ks_next>{}, std::integral_constant<int, r - 4>{});
                     }
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
@@ -549,7 +566,7 @@ struct az_net {
     float *epi = nullptr, *fc_b = nullptr, *skip_w = nullptr, *logits = nullptr;
     float in_affine[16];
     int max_boards = 0;
-    int bpw_max = 0, lds_head = 0, n_ot = 0;
+    int bpw_max = 0, lds_head = 0, n_ot = 0, r3 = 16;
 };
 static std::string g_net_err;
 
@@ -655,7 +672,6 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
         delete n;
         return AZ_E_HIP;
     }
-    size_t cw = (size_t)2 * d.n_blocks * AZ_NET_KSTEPS * 4 * 64 * 8 * 2;
     size_t fw = (size_t)n->n_ot * (HW * AZ_NET_XOUT_C / 32) * 64 * 8 * 2, fb = (size_t)n->n_ot * 16 * 4;
     int rc = AZ_OK;
     auto up = [&](void **dst, const void *src, size_t bytes) {
@@ -665,20 +681,34 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
             rc = AZ_E_NOMEM;
         }
     };
-    {   // device layout: [conv 0 compacted to AZ_NET_K0STEPS k-steps][conv 1 ..][..] (ABI layout: 16 k-steps each).
-        // Conv 0 sees the input planes only (channel octet 0), i.e. ABI groups 7*tap; they become groups 0..8.
-        const size_t conv_b = (size_t)AZ_NET_KSTEPS * 4 * 64 * 8 * 2, c0_b = (size_t)AZ_NET_K0STEPS * 4 * 64 * 8 * 2;
-        std::vector<unsigned char> dev(c0_b + cw - conv_b, 0);
+    {   // device layout: [conv 0 compacted to AZ_NET_K0STEPS k-steps][conv 1 ..][..], one RECORD per k-step: output-channel
+        // tiles 0..2 as in the ABI layout (3 KiB), tile 3 with only its stored rows (see WRec).  Conv 0 sees the input
+        // planes only (channel octet 0), i.e. ABI groups 7*tap; they become groups 0..8 of its 4 k-steps.
+        n->r3 = d.n_filters <= 50 ? 2 : 16;
+        const int rows = n->r3 < 16 ? n->r3 + 1 : 16, rec = 3 * 1024 + 4 * rows * 16;
+        const int n_convs = 2 * d.n_blocks;
+        const size_t conv_b = (size_t)AZ_NET_KSTEPS * 4096;
+        std::vector<unsigned char> dev((size_t)(AZ_NET_K0STEPS + (size_t)(n_convs - 1) * AZ_NET_KSTEPS) * rec + 1024, 0);
         const unsigned char *src = (const unsigned char *)d.conv_w;
+        auto put_record = [&](unsigned char *dst, const unsigned char *ks4k) { // ks4k: [4 mt][64 lanes][16 B]
+            memcpy(dst, ks4k, 3 * 1024);
+            for (int q = 0; q < 4; q++)
+                for (int r = 0; r < (n->r3 < 16 ? n->r3 : 16); r++)
+                    memcpy(dst + 3 * 1024 + (q * rows + r) * 16, ks4k + 3 * 1024 + (q * 16 + r) * 16, 16);
+        };
+        std::vector<unsigned char> c0(AZ_NET_K0STEPS * 4096, 0); // conv 0 compacted, still in 4 KiB k-steps
         for (int ks = 0; ks < AZ_NET_K0STEPS; ks++)
             for (int mt = 0; mt < 4; mt++)
                 for (int lane = 0; lane < 64; lane++) {
                     int g = 4 * ks + (lane >> 4);
                     if (g >= 9) continue;
                     int go = 7 * g, oks = go >> 2, olane = (go & 3) * 16 + (lane & 15);
-                    memcpy(&dev[(((size_t)ks * 4 + mt) * 64 + lane) * 16], src + (((size_t)oks * 4 + mt) * 64 + olane) * 16, 16);
+                    memcpy(&c0[(((size_t)ks * 4 + mt) * 64 + lane) * 16], src + (((size_t)oks * 4 + mt) * 64 + olane) * 16, 16);
                 }
-        memcpy(&dev[c0_b], src + conv_b, cw - conv_b);
+        size_t off = 0;
+        for (int ks = 0; ks < AZ_NET_K0STEPS; ks++, off += rec) put_record(&dev[off], &c0[(size_t)ks * 4096]);
+        for (int c = 1; c < n_convs; c++)
+            for (int ks = 0; ks < AZ_NET_KSTEPS; ks++, off += rec) put_record(&dev[off], src + (size_t)c * conv_b + (size_t)ks * 4096);
         up((void **)&n->conv_w, dev.data(), dev.size());
     }
     {   // [conv][3][64] (ABI) -> [conv][4][64] with the NEXT conv's bias in row 3 (what the kernel's ring slot holds)
@@ -722,15 +752,18 @@ extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
     return AZ_OK;
 }
 
-template <int NT, int CK, int WAVES, bool RP1> static hipError_t launch_tower_rp(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
+template <int NT, int CK, int WAVES, bool RP1, int R3> static hipError_t launch_tower_r3(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
     static bool attr_set[16] = {false};
     if (!attr_set[n->d.device & 15]) {
-        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT, CK, WAVES, RP1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT, CK, WAVES, RP1, R3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (s != hipSuccess) return s;
         attr_set[n->d.device & 15] = true;
     }
-    hipLaunchKernelGGL((az_tower_kernel<NT, CK, WAVES, RP1>), dim3(grid), dim3(WAVES * 64), lds, st, tp);
+    hipLaunchKernelGGL((az_tower_kernel<NT, CK, WAVES, RP1, R3>), dim3(grid), dim3(WAVES * 64), lds, st, tp);
     return hipGetLastError();
+}
+template <int NT, int CK, int WAVES, bool RP1> static hipError_t launch_tower_rp(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
+    return n->r3 == 2 ? launch_tower_r3<NT, CK, WAVES, RP1, 2>(n, tp, grid, lds, st) : launch_tower_r3<NT, CK, WAVES, RP1, 16>(n, tp, grid, lds, st);
 }
 template <int NT, int CK, int WAVES> static hipError_t launch_tower(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
     // row-pair tiles (row stride 8), one board per wave, every tile of the wave on that board

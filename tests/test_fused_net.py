@@ -43,6 +43,8 @@ def _nets():
         "bt8_2block": (bt8, Net([3, 8, 8], 768, n_blocks=2, n_filters=50).eval()),
         "bt5x4_3block": (games.load_game("breakthrough(rows=5,columns=4)"),
                          Net([3, 5, 4], 240, n_blocks=3, n_filters=32).eval()),
+        # > 50 filters: output-channel tile 3 is streamed in full (the <= 50 case streams 2 of its 16 rows)
+        "c4_56f_2block": (c4, Net([3, 6, 7], 7, n_blocks=2, n_filters=56).eval()),
         # 4 rows = 2 row-pair tiles per board: the 3-tile kernel must mask its third tile
         "bt4x5_2block": (games.load_game("breakthrough(rows=4,columns=5)"),
                          Net([3, 4, 5], 240, n_blocks=2, n_filters=40).eval()),
@@ -76,7 +78,8 @@ def test_net_matches_reference_golden_outputs():
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,n", [("c4_ckpt", 24), ("c4_ckpt", 1), ("c4_ckpt", 157), ("bt6_ckpt", 40),
                                    ("c4_10block", 300), ("bt8_2block", 37), ("bt5x4_3block", 50),
-                                   ("bt4x5_2block", 3), ("bt4x5_2block", 130), ("c4_10block", 4096)])
+                                   ("bt4x5_2block", 3), ("bt4x5_2block", 130), ("c4_10block", 4096),
+                                   ("c4_56f_2block", 33), ("c4_56f_2block", 2100)])
 def test_fused_forward_matches_torch(tag, n):
     game, net = _nets()[tag]
     boards = _random_boards(game, n, 7)
