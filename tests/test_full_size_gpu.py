@@ -8,6 +8,8 @@
   visits below the root, and after a move to a child with N_c visits the next root carries S + max(N_c - 1, 0);
 * slot-count invariance: the RNG streams are keyed by game id, the net evaluates each board independently, so the
   same seed played on 4096 slots and on 1024 slots (four refills) yields identical records, bit for bit;
+* tick-scheduling invariance: chaining one playout per tick (time window off) instead of the default budget yields the
+  same records;
 * replay store at that size: the number of unique examples equals the number of distinct action histories, the
   unique list is in first-occurrence order, singletons keep the reference's pi arithmetic exactly, and the mean
   value target over all examples is preserved by the averaging (count-weighted).
@@ -23,13 +25,13 @@ pytestmark = pytest.mark.gpu
 S, G, N_GAMES = 400, 4096, 4096
 
 
-def _play(n_slots, n_games, seed, keep_engine=False):
+def _play(n_slots, n_games, seed, keep_engine=False, **engine_kw):
     from alphazero_openspiel_amd import engine as E, fusednet
     from alphazero_openspiel_amd.network import Net
     torch.manual_seed(0)
     net = Net([3, 6, 7], 7, n_blocks=10, n_filters=50).eval()
     fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots)
-    eng = E.SelfPlayEngine("connect_four", n_slots, n_playouts=S, max_games=n_games, seed=seed, device=0)
+    eng = E.SelfPlayEngine("connect_four", n_slots, n_playouts=S, max_games=n_games, seed=seed, device=0, **engine_kw)
     prog = E.run_selfplay(eng, fn, n_games, use_graph=True)
     assert prog["games_done"] == n_games and prog["error_flags"] == 0
     ex = eng.export()
@@ -97,6 +99,22 @@ def test_records_do_not_depend_on_the_number_of_slots(full_run):
     assert (ex["states"][live_ply] == ex_small["states"][live_ply]).all()
     assert (ex["child_visits"][live_child] == ex_small["child_visits"][live_child]).all()
     assert (ex["child_action"][live_child] == ex_small["child_action"][live_child]).all()
+
+
+def test_records_do_not_depend_on_tick_scheduling(full_run):
+    """How many NN-free playouts a slot chains per tick (count cap, time window) is scheduling only: one playout per
+    tick with the window off gives the same games as the defaults, bit for bit (first 512 games compared)."""
+    ex, _, _ = full_run
+    n = 512
+    ex_b, prog_b = _play(512, n, seed=2024, max_sims_per_tick=1, chain_window_us=-1)
+    assert (ex["game_len"][:n] == ex_b["game_len"]).all() and (ex["game_ret0"][:n] == ex_b["game_ret0"]).all()
+    live_ply = np.arange(ex_b["move"].shape[1])[None, :] < ex_b["game_len"][:, None]
+    live_child = live_ply[:, :, None] & (np.arange(ex_b["child_visits"].shape[2])[None, None, :]
+                                         < ex_b["n_children"][:, :, None])
+    for k in ("move", "n_children", "value"):
+        assert (ex[k][:n][live_ply] == ex_b[k][live_ply]).all(), k
+    assert (ex["child_visits"][:n][live_child] == ex_b["child_visits"][live_child]).all()
+    assert (ex["states"][:n][live_ply] == ex_b["states"][live_ply]).all()
 
 
 def test_replay_store_at_full_size(full_run):
