@@ -96,14 +96,16 @@ template <int OFF> __device__ __forceinline__ void lds_read_f4_off(f32x4 &dst, u
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
 }
 __device__ __forceinline__ void keep_alive(const f32x4 &v) { asm volatile("" ::"v"(v)); }
+// (ablation stand-in for a fragment read: defines the register, touches nothing)
+__device__ __forceinline__ void fake_read128(half8 &dst, unsigned lds_byte_addr) { asm volatile("" : "=v"(dst) : "v"(lds_byte_addr)); }
 #ifdef AZ_ABL_NOA
-#define READ_A(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr))
+#define READ_A(dst, addr, off) fake_read128(dst, addr)
 #else
 #define READ_A(dst, addr, off) lds_read128_off<(off)>(dst, addr)
 #endif
 #ifdef AZ_ABL_NOB
-#define READ_B(dst, addr) asm volatile("" : "=v"(dst) : "v"(addr))
-#define READ_B_OFF(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr))
+#define READ_B(dst, addr) fake_read128(dst, addr)
+#define READ_B_OFF(dst, addr, off) fake_read128(dst, addr)
 #else
 #define READ_B(dst, addr) lds_read128(dst, addr)
 #define READ_B_OFF(dst, addr, off) lds_read128_off<(off)>(dst, addr)
