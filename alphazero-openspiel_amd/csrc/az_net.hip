@@ -420,10 +420,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
 #ifdef AZ_EXPERIMENTAL_PP
 // ------------------------------------------------------------------------------------------------
 // EXPERIMENTAL, not built by default (make ABL=-DAZ_EXPERIMENTAL_PP, then AZ_TOWER_PP=1 at run time).  Status at the end of
-// round 1: results bit-identical to az_tower_kernel, but 323 us vs 209 us per 4096 boards - two boards' accumulators and
-// residual streams (192 registers) + fragments + tables overflow the 256 architectural VGPRs, the compiler parks the
-// residual stream in scratch memory in the middle of the MFMA stream and re-fuses the epilogue micro-steps.  It needs
-// explicit AGPR residency for the idle board's state (or a hand-written slice in assembly) to show its worth.
+// round 1: results bit-identical to az_tower_kernel; 237 us vs 211 us per 4096 boards (tools/net_microbench.py, same box).
+// 415 registers (256 VGPR + 159 AGPR), no scratch - but only after forcing every lambda inline and writing the conv loop
+// as straight-line pairs (with a kind dispatch inside the loop hipcc spilled loop-invariant tables to scratch: 323 us).
+// PMC (per wave): MFMA pipe busy 54 % of the wave's life, 23 % parked in s_waitcnt / barriers (with one wave per SIMD every
+// LDS-latency and barrier stall is exposed), 1.5 VALU instructions per MFMA against 1.0 in the 8-wave kernel (AGPR moves,
+// un-hoisted addresses), so the epilogue slices are VALU-issue bound.  Next: a third fragment buffer for the A operand
+// (needs ~16 registers back), store addresses in AGPRs instead of recomputed, parameter-free kind-0 epilogues.
 // "Ping-pong" tower: 4 waves per workgroup (one per SIMD), TWO boards per wave, same weight stream and barriers as the
 // 8-wave kernel above.  The two boards take turns on the matrix pipe, slice by slice (a slice = the k-steps of one
 // weight chunk for one board), and the epilogue of the board that has just finished a conv is cut into 2-instruction
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_pp_kernel(TowerParams p) {
     // KIND 0: conv1 of a block (u = lrelu(acc)), 1: conv2 (x += acc; a = lrelu(sc*x + sh)), 2: last conv (x += acc -> HBM).
     // Step e of board OB: tile = e / PH (mt-major), phase = e % PH; a couple of VALU instructions per phase.  The first step
     // of output-channel tile mt also issues the (untracked) LDS reads of tile mt + 1's parameters.
-    auto ep_read_mt = [&](unsigned ep_base, auto mt_c, auto kind_c) { // 3 reads (kind 1) or 1 (kinds 0, 2: next bias only)
+    auto ep_read_mt = [&](unsigned ep_base, auto mt_c, auto kind_c) __attribute__((always_inline)) { // 3 reads (kind 1) or 1 (kinds 0, 2: next bias only)
         constexpr int mt = decltype(mt_c)::value, KIND = decltype(kind_c)::value;
         if constexpr (KIND == 1) {
             lds_read_f4_off<256 + mt * 64>(ep_sc[mt & 1], ep_base);
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_pp_kernel(TowerParams p) {
         }
         lds_read_f4_off<768 + mt * 64>(ep_nb[mt & 1], ep_base);
     };
-    auto epi_micro = [&](auto kind_c, auto ob_c, auto e_c, unsigned ep_base) {
+    auto epi_micro = [&](auto kind_c, auto ob_c, auto e_c, unsigned ep_base) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_c)::value, OB = decltype(ob_c)::value, e = decltype(e_c)::value;
         constexpr int PH = KIND == 0 ? 4 : (KIND == 1 ? 6 : 3);
         if constexpr (e >= 0 && e < 12 * PH) {
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_pp_kernel(TowerParams p) {
     //      parameters read at the slice start have landed by then, and the last k-step's prefetch of the other board's
     //      next B fragments comes after all of its stores.
     auto slice = [&](auto b_c, auto ckl_c, auto kbase_c, const auto &kf, auto foc_c, auto next_c, auto nkb_c, const auto &nkf,
-                     auto ek_c, int conv, int conv_e, auto veryfirst_c) {
+                     auto ek_c, int conv, int conv_e, auto veryfirst_c) __attribute__((always_inline)) {
         constexpr int B = decltype(b_c)::value, OB = 1 - B, CKL = decltype(ckl_c)::value, KBASE = decltype(kbase_c)::value;
         constexpr bool FOC = decltype(foc_c)::value, VERYFIRST = decltype(veryfirst_c)::value;
         constexpr int NEXT = decltype(next_c)::value, NKB = decltype(nkb_c)::value, EK = decltype(ek_c)::value;
@@ -670,30 +673,35 @@ __global__ __launch_bounds__(256, 1) void az_tower_pp_kernel(TowerParams p) {
                 constexpr int g = ksl * 12 + j;       // slot in the slice
                 constexpr int e = g - 12;             // epilogue step issued in this slot (k-steps 1 .. CKL-2 only)
                 constexpr bool epi_here = EK >= 0 && ksl >= 1 && ksl <= CKL - 2;
-                constexpr int issued_next = j < n_next ? j : n_next;
+                constexpr int RPS = 2; // fragment reads issued per MFMA slot: with one wave per SIMD nothing else hides LDS latency,
+                                       // so the next k-step's reads go out in the first slots of this one
+                constexpr int issued_next = RPS * j < n_next ? RPS * j : n_next;
                 if constexpr (mt == 0) {
-                    // LDS operations younger than the fragment B_nt of this k-step (issued in slot g0 = (ksl-1)*12 + 4 + nt
+                    // LDS operations younger than the fragment B_nt of this k-step (issued in slot g0 = (ksl-1)*12 + (4+nt)/RPS
                     // of this slice, or at the end of the previous slice / the slice start for k-step 0):
                     //   the later fragments of this k-step, the next k-step's reads issued so far, the epilogue's LDS
                     //   operations from slot g0 on, and for k-step 0 the first parameter reads.
                     constexpr int after = (FOC && ksl == 0) ? 0 : NT - 1 - nt;
-                    constexpr int g0 = (ksl - 1) * 12 + 4 + nt;
+                    constexpr int g0 = (ksl - 1) * 12 + (4 + nt) / RPS;
                     constexpr int eops = ksl >= 1 ? pp_ops_between(EK, CKL, g0, g) : 0;
                     constexpr int extra = (ksl == 0 && !FOC) ? N_EP : 0; // (FOC: the parameter reads precede the A reads)
                     wait_lgkm(after + issued_next + eops + extra);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (j < n_next) {
-                    if constexpr (more_here) {
-                        if constexpr (j < 4) READ_A(a[nxt][j], j < 3 ? wbl : wbl3, (ksl + 1) * REC + j * 1024);
-                        else READ_B_OFF(bf[nxt][j - 4], nb_addr, (j - 4) * 256);
-                    } else if constexpr (NEXT == 1) { // the other board starts over on this chunk
-                        if constexpr (j < 4) READ_A(a[nxt][j], j < 3 ? wbl : wbl3, j * 1024);
-                        else READ_B_OFF(bf[nxt][j - 4], nb_addr, (j - 4) * 256);
-                    } else { // NEXT == 2: next chunk, B only (its A fragments are read after the barrier)
-                        READ_B_OFF(bf[nxt][j], nb_addr, j * 256);
+                static_for<RPS>([&](auto rr_c) {
+                    constexpr int r = RPS * j + decltype(rr_c)::value; // read index in the next k-step's order A0..A3, B0..B2
+                    if constexpr (r < n_next) {
+                        if constexpr (more_here) {
+                            if constexpr (r < 4) READ_A(a[nxt][r], r < 3 ? wbl : wbl3, (ksl + 1) * REC + r * 1024);
+                            else READ_B_OFF(bf[nxt][r - 4], nb_addr, (r - 4) * 256);
+                        } else if constexpr (NEXT == 1) { // the other board starts over on this chunk
+                            if constexpr (r < 4) READ_A(a[nxt][r], r < 3 ? wbl : wbl3, r * 1024);
+                            else READ_B_OFF(bf[nxt][r - 4], nb_addr, (r - 4) * 256);
+                        } else { // NEXT == 2: next chunk, B only (its A fragments are read after the barrier)
+                            READ_B_OFF(bf[nxt][r], nb_addr, r * 256);
+                        }
                     }
-                }
+                });
                 if constexpr (epi_here) epi_micro(ek_c, std::integral_constant<int, OB>{}, std::integral_constant<int, e>{}, ep_base);
                 acc[B][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], bf[cur][nt], acc[B][mt][nt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -702,7 +710,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_pp_kernel(TowerParams p) {
         if constexpr (EK >= 0) ep_keep();
     };
     // a whole epilogue, not overlapped (board 0 after conv 0; the last board after the last conv)
-    auto epilogue_now = [&](auto kind_c, auto ob_c, int conv_e) {
+    auto epilogue_now = [&](auto kind_c, auto ob_c, int conv_e) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_c)::value;
         const unsigned ep_base = lds_base + p.off_epi + (conv_e & 1) * 1024 + q * 16;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -734,20 +742,24 @@ __global__ __launch_bounds__(256, 1) void az_tower_pp_kernel(TowerParams p) {
     epilogue_now(I0{}, I0{}, 0);
     slice(I1{}, IK0{}, I0{}, koff0, F{}, I2{}, I0{}, koff, IM{}, 0, 0, F{});
     chunk++;
-    for (int conv = 1; conv < p.n_convs; conv++) {
-        const bool odd = conv & 1; // conv2 of a block: its epilogue is kind 1 (2 for the last); the previous conv's is kind 0
+    // the convs after conv 0 come in pairs (conv2 of a block, conv1 of the next one): straight-line code, no kind dispatch
+    auto conv_slices = [&](int conv, auto ek_prev_c, auto ek_own_c, auto last_c) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_c)::value;
         // chunk (conv, 0): b0 with the epilogue of b1's previous conv, then b1
-        if (odd) slice(I0{}, ICK{}, I0{}, koff, T{}, I1{}, I0{}, koff, I0{}, conv, conv - 1, F{});
-        else slice(I0{}, ICK{}, I0{}, koff, T{}, I1{}, I0{}, koff, I1{}, conv, conv - 1, F{});
+        slice(I0{}, ICK{}, I0{}, koff, T{}, I1{}, I0{}, koff, ek_prev_c, conv, conv - 1, F{});
         slice(I1{}, ICK{}, I0{}, koff, F{}, I2{}, ICK{}, koff, IM{}, conv, 0, F{});
         chunk++;
         // chunk (conv, 1): b0, then b1 with the epilogue of b0's conv
         slice(I0{}, ICK{}, ICK{}, koff, T{}, I1{}, ICK{}, koff, IM{}, conv, 0, F{});
-        if (conv == p.n_convs - 1) slice(I1{}, ICK{}, ICK{}, koff, F{}, I0{}, I0{}, koff, I2{}, conv, conv, F{});
-        else if (odd) slice(I1{}, ICK{}, ICK{}, koff, F{}, I2{}, I0{}, koff, I1{}, conv, conv, F{});
-        else slice(I1{}, ICK{}, ICK{}, koff, F{}, I2{}, I0{}, koff, I0{}, conv, conv, F{});
+        if constexpr (LAST) slice(I1{}, ICK{}, ICK{}, koff, F{}, I0{}, I0{}, koff, ek_own_c, conv, conv, F{});
+        else slice(I1{}, ICK{}, ICK{}, koff, F{}, I2{}, I0{}, koff, ek_own_c, conv, conv, F{});
         chunk++;
+    };
+    for (int conv = 1; conv + 2 < p.n_convs; conv += 2) {
+        conv_slices(conv, I0{}, I1{}, F{});     // conv2 of a block: previous epilogue kind 0, its own kind 1
+        conv_slices(conv + 1, I1{}, I0{}, F{}); // conv1 of the next block
     }
+    conv_slices(p.n_convs - 1, I0{}, I2{}, T{}); // the last conv: its epilogue writes the tower output
     epilogue_now(I2{}, I1{}, p.n_convs - 1);
 }
 
