@@ -963,10 +963,11 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     p.chain_clocks = c.chain_window_us < 0 ? 0 : (c.chain_window_us > 0 ? c.chain_window_us : 10) * 100;
     p.manual_moves = c.manual_moves ? 1 : 0;
     p.need_per_move = (uint32_t)((c.n_playouts + 1) * p.maxc);
-    // default pool: room for ~24 searches (or the whole game if shorter) so that re-root compaction is rare
-    // (measured, connect_four S=400, 4096 slots: 6x -> 10k compactions per 4096 games and a 78 us move kernel;
-    // 24x -> 470 compactions, 6 us), capped so that the pools take at most half of the free HBM.
-    int64_t moves_room = p.max_plies < 24 ? p.max_plies : 24;
+    // default pool: room for 48 searches, or for the whole game if it is shorter (connect_four: 42 plies -> a slot never
+    // compacts; every compaction is a ~100-400 us single-wave Cheney copy that holds the whole launch), capped so that the
+    // pools take at most half of the free HBM.  Measured, connect_four S=400, 4096 slots: 6 searches 10k compactions per
+    // 4096 games, 24 searches 820, whole game none: +1.7 % games/s over 24, 31 GB instead of 18 GB.
+    int64_t moves_room = p.max_plies < 48 ? p.max_plies : 48;
     int64_t cap = c.nodes_per_slot > 0 ? c.nodes_per_slot : moves_room * p.need_per_move + 64;
     if (c.nodes_per_slot <= 0) {
         size_t free_b = 0, total_b = 0;
