@@ -10,13 +10,15 @@
 // reference's Python-float arithmetic: given the same (priors, value) inputs and the same random
 // draws, visit counts and Q values are bit-identical to mcts.py.
 //
-// HBM layout (all SoA, index = (slot*2 + half)*cap + node):
+// HBM layout: node pools of 32-byte records (AzNode, az_engine_internal.h), index = (slot*2 + half)*cap + node:
 //   N   u32   visit count                       Q  f64  mean value (viewpoint of the player who moved in)
-//   P   f64   prior                              C0 u32  index of first child (children are contiguous,
-//   META u32  action (low 16) | n_children<<16          ascending action = dict insertion order of mcts.py:62-64)
-// so one select level is ONE coalesced read of {N,Q,P,C0,META}[c0 .. c0+n) by lanes 0..n-1.
+//   C0  u32   index of first child              P  f64  prior
+//   META u32  action (low 16) | n_children<<16  (children are contiguous, ascending action = dict insertion order of
+//                                                mcts.py:62-64)
+// so one select level is ONE contiguous read of nodes [c0 .. c0+n) by lanes 0..n-1 (two 16-byte loads per lane).
 // Each slot has two pool halves; re-rooting compacts the kept subtree into the other half
 // (Cheney copy, breadth-first) when the free tail could not hold another search.
+// One launch per tick (az_advance_kernel): the agent's move step is the cold prologue of the slot's next tick.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
