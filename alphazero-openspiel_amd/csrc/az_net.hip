@@ -103,6 +103,15 @@ __device__ __forceinline__ void fake_read128(half8 &dst, unsigned lds_byte_addr)
 #else
 #define READ_A(dst, addr, off) lds_read128_off<(off)>(dst, addr)
 #endif
+template <int OFF> __device__ __forceinline__ void lds_read32_off(unsigned &dst, unsigned lds_byte_addr) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
+}
+__device__ __forceinline__ void fake_read32(unsigned &dst, unsigned lds_byte_addr) { asm volatile("" : "=v"(dst) : "v"(lds_byte_addr)); }
+#ifdef AZ_ABL_NOB
+#define READ_B32_OFF(dst, addr, off) fake_read32(dst, addr)
+#else
+#define READ_B32_OFF(dst, addr, off) lds_read32_off<(off)>(dst, addr)
+#endif
 #ifdef AZ_ABL_NOB
 #define READ_B(dst, addr) fake_read128(dst, addr)
 #define READ_B_OFF(dst, addr, off) fake_read128(dst, addr)
@@ -139,8 +148,13 @@ template <int NT, int CK, int WAVES, bool RP1, int R3>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int REC = WRec<R3>::BYTES;
-    constexpr int CHUNK_B = CK * REC;        // bytes of one chunk in the stream
+    constexpr int CHUNK_B = CK * REC;        // bytes of one (full) chunk in the stream
     constexpr int CHUNK_S = CK * 4 * 64 * 16; // stride of the two chunk buffers in LDS (the host's layout)
+    // <= 50 filters (R3 < 16): K is grouped into 15 k-steps instead of 16.  Groups 0..53 = (tap, channel octet 0..5);
+    // groups 54, 55 zero; the last k-step takes channels 48, 49 of all nine taps: element j of group q < 3 is channel
+    // 48 + (j & 1) at tap 4 q + j / 2 - its B fragment is four 4-byte reads (one per tap) instead of one 16-byte read.
+    constexpr bool L15 = R3 < 16;
+    constexpr int NKS = L15 ? 15 : AZ_NET_KSTEPS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l15 = lane & 15;
     const int plane_b = p.rcells * OCT_B, region_b = N_OCT * plane_b;
@@ -180,11 +194,27 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
     int koff[AZ_NET_KSTEPS]; // byte offset (tap shift + octet plane) of this lane's k-group in each k-step
 #pragma unroll
     for (int ks = 0; ks < AZ_NET_KSTEPS; ks++) {
-        int g = 4 * ks + q;
-        int tap = g / 7, c8 = g - tap * 7;
+        int g = 4 * ks + q, tap, c8;
+        bool zero;
+        if (L15) {
+            tap = g / 6, c8 = g - tap * 6;
+            zero = g >= 54;
+        } else {
+            tap = g / 7, c8 = g - tap * 7;
+            zero = g == 63;
+        }
         int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        koff[ks] = g == 63 ? 0 : (dy * p.rs + dx) * OCT_B + c8 * plane_b; // group 63: zero weights, any finite data
-        if (RP1) koff[ks] += (int)lds_base + pos_addr[0];                 // the full LDS address of tile 0's fragment
+        koff[ks] = zero ? 0 : (dy * p.rs + dx) * OCT_B + c8 * plane_b; // zero groups: zero weights, any finite data
+        if (RP1) koff[ks] += (int)lds_base + pos_addr[0];              // the full LDS address of tile 0's fragment
+    }
+    int ksp[4]; // L15: the four taps of this lane's group in the last k-step (channels 48, 49 = first 4 bytes of octet 6)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int tap = 4 * q + i;
+        tap = tap > 8 ? 8 : tap; // (taps past the ninth carry zero weights)
+        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        ksp[i] = (dy * p.rs + dx) * OCT_B + 6 * plane_b;
+        if (RP1) ksp[i] += (int)lds_base + pos_addr[0];
     }
     // conv 0 reads the 4 input planes only (octet 0): K = 9 taps x 1 octet, packed as ONE 4-k-step chunk
     // (group g < 9 = tap g of octet 0, groups 9..15 zero weights) instead of 16 k-steps that are 6/7 zeros.
@@ -234,9 +264,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
 
     // ---- weight stream: chunk c -> buffer c&1, by LDS-DMA (global_load_lds, 16 B/lane).  Chunk 0 = conv 0 (4 k-steps,
     // 16 KiB), chunk c >= 1 = CK k-steps of the 16-k-step convs that follow, contiguous in the device buffer.
-    constexpr int PARTS = AZ_NET_KSTEPS / CK;
+    constexpr int PARTS = (NKS + CK - 1) / CK; // chunks per conv (the last one is shorter when NKS = 15)
     constexpr int C0_B = AZ_NET_K0STEPS * REC;
     static_assert(CK % 2 == 0 && AZ_NET_K0STEPS % 2 == 0, "fragment buffer parity relies on an even chunk length");
+    static_assert((PARTS & (PARTS - 1)) == 0 && NKS - (PARTS - 1) * CK >= 3, "chunk index arithmetic / the last two k-steps share a chunk");
     static_assert(CK * 4 * 1024 <= 65536, "A-fragment offsets (relative to the chunk base) must fit the ds offset field");
     static_assert(C0_B <= CHUNK_B && REC % 16 == 0 && ((CHUNK_B + 1023) & ~1023) <= CHUNK_S, "chunk must fit its LDS buffer");
     const int n_chunks = 1 + (p.n_convs - 1) * PARTS;
@@ -251,8 +282,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                                                  (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
         }
     };
-    auto issue_chunk = [&](int c) { // c >= 1
-        issue_bytes((const unsigned char *)p.conv_w + C0_B + (size_t)(c - 1) * CHUNK_B, lds + (c & 1) * CHUNK_S,
+    auto issue_chunk = [&](int c) { // c >= 1: chunk (c - 1) % PARTS of conv 1 + (c - 1) / PARTS.  A short last chunk is fetched at full
+                                    // length (it runs into the next conv's records; the stream is padded at its end)
+        const int ci = (c - 1) / PARTS, part = (c - 1) & (PARTS - 1);
+        issue_bytes((const unsigned char *)p.conv_w + C0_B + ((size_t)ci * NKS + (size_t)part * CK) * REC, lds + (c & 1) * CHUNK_S,
                     std::integral_constant<int, CHUNK_B>{});
     };
     issue_bytes((const unsigned char *)p.conv_w, lds, std::integral_constant<int, C0_B>{});
@@ -264,16 +297,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
 
     int chunk = 0;
     // one conv = NPARTS chunks of CKL k-steps (kf: this lane's k-group offsets) + its epilogue
-    auto conv_step = [&](int conv, auto nparts_c, auto ckl_c, const auto &kf, auto is_first_c) {
-        constexpr int NPARTS = decltype(nparts_c)::value, CKL = decltype(ckl_c)::value;
+    auto conv_step = [&](int conv, const auto &kf, auto is_first_c) {
         constexpr bool IS_FIRST = decltype(is_first_c)::value;
+        constexpr int NPARTS = IS_FIRST ? 1 : PARTS;
+        constexpr int NKSC = IS_FIRST ? AZ_NET_K0STEPS : NKS;      // k-steps of this conv
+        constexpr bool HAS_SPECIAL = L15 && !IS_FIRST;             // its last k-step is the 4-byte-gather one
         half8 a[2][4], b[2][NT]; // fragment double buffer: k-step s+1 is fetched while s is multiplied
+        unsigned bsp[NT][4];     // B fragments of the gather k-step, dword by dword
         // This conv's epilogue parameters for the lane's 4 x 4 channels (scale, shift, next conv's bias): fetched from the
         // ring during the LAST k-step, when the other fragment buffer is dead, so the epilogue never waits on LDS.
         f32x4 ep_sc[4], ep_sh[4], ep_nb[4];
         const unsigned ep_base = lds_base + p.off_epi + (conv & 1) * 1024 + q * 16;
         static_for<NPARTS>([&](auto part_c) {
             constexpr int part = decltype(part_c)::value;
+            constexpr int CKL = part == NPARTS - 1 ? NKSC - part * CK : CK; // k-steps in this chunk
             // The weight fragments are read by untracked asm, so hipcc sees no consumer of the LDS-DMA and would NOT wait
             // for it: wait by hand.  After the barrier every wave's pieces of this chunk have landed and the other
             // buffer is free for the next chunk's DMA.
@@ -296,15 +333,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             const unsigned wbl3 = R3 == 16 ? wbl
                                            : lds_base + (chunk & 1) * CHUNK_S +
                                                  (q * WRec<R3>::ROWS + (l15 < WRec<R3>::ROWS - 1 ? l15 : WRec<R3>::ROWS - 1)) * 16;
-            // B fragment of column tile nt in k-step ks (ks compile-time)
+            // B fragment of column tile nt in k-step ks (ks compile-time, index into kf)
             auto read_b = [&](half8 &dst, auto ks_c, auto nt_c) {
                 constexpr int ks = decltype(ks_c)::value, nt = decltype(nt_c)::value;
                 if constexpr (RP1) READ_B_OFF(dst, (unsigned)kf[ks], nt * 256);
                 else READ_B(dst, lds_base + pos_addr[nt] + opaque(kf[ks])); // opaque: keep the NT*16 sums out of LICM's hands
             };
-            // Read order inside a k-step: A0..A3, B0, B1, ... (read index: A_mt = mt, B_nt = 4 + nt).  LDS returns in
-            // order, so before the MFMAs of column tile nt it is enough to wait until at most (reads issued after
-            // B_nt) are outstanding: counted s_waitcnt instead of lgkmcnt(0).
+            // dword i (tap 4q + i, channels 48, 49) of the gather k-step's B fragment for column tile nt
+            auto read_bsp = [&](unsigned &dst, auto i_c, auto nt_c) {
+                constexpr int i = decltype(i_c)::value, nt = decltype(nt_c)::value;
+                if constexpr (RP1) READ_B32_OFF(dst, (unsigned)ksp[i], nt * 256);
+                else READ_B32_OFF(dst, lds_base + pos_addr[nt] + opaque(ksp[i]), 0);
+            };
+            // Read order inside a k-step: A0..A3, B0, B1, ... (read index: A_mt = mt, B_nt = 4 + nt; gather k-step: the four
+            // dwords of B_nt are reads 4 + 4 nt .. 7 + 4 nt).  LDS returns in order, so before the MFMAs of column tile nt it
+            // is enough to wait until at most (reads issued after B_nt) are outstanding: counted s_waitcnt, not lgkmcnt(0).
             static_for<4>([&](auto mt_c) {
                 constexpr int mt = decltype(mt_c)::value;
                 READ_A(a[0][mt], mt < 3 ? wbl : wbl3, mt * 1024);
@@ -312,13 +355,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             if constexpr (part == 0) // later chunks of a conv had their B fragments fetched before the barrier
                 static_for<NT>([&](auto nt_c) { read_b(b[0][decltype(nt_c)::value], std::integral_constant<int, 0>{}, nt_c); });
             static_for<CKL>([&](auto ksl_c) {
-                constexpr int ksl = decltype(ksl_c)::value;
+                constexpr int ksl = decltype(ksl_c)::value, ksg = part * CK + ksl; // k-step in the chunk / in the conv
                 constexpr int cur = ksl & 1, nxt = cur ^ 1;
                 constexpr bool more_here = ksl + 1 < CKL;                   // next k-step is in this chunk: A and B
                 constexpr bool more_next = !more_here && part + 1 < NPARTS; // next k-step is in the next chunk: B only
-                constexpr int n_next = more_here ? NT + 4 : (more_next ? NT : 0); // reads to issue during this k-step
+                constexpr bool cur_gather = HAS_SPECIAL && ksg == NKSC - 1;  // this k-step multiplies the gathered fragments
+                constexpr bool next_gather = HAS_SPECIAL && ksg + 1 == NKSC - 1; // ... the next one does (same chunk)
+                constexpr int n_next = more_here ? (next_gather ? 4 + 4 * NT : NT + 4) : (more_next ? NT : 0); // reads to issue now
+                constexpr int RPS = (n_next + 4 * NT - 1) / (4 * NT) > 1 ? (n_next + 4 * NT - 1) / (4 * NT) : 1; // per MFMA slot
                 constexpr bool first_of_chunk = ksl == 0;
-                constexpr int ks_next = (more_here || more_next) ? part * CKL + ksl + 1 : 0;
+                constexpr int ks_next = (more_here || more_next) ? ksg + 1 : 0;
                 constexpr bool last_of_conv = !more_here && !more_next;
                 // (conv 0 is always a conv1-type epilogue: next bias only.  An asynchronous read into a register nothing
                 // consumes would let the compiler hand that register to something else while the data is still in flight.)
@@ -335,21 +381,32 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                 static_for<4 * NT>([&](auto j_c) {
                     constexpr int j = decltype(j_c)::value;
                     constexpr int nt = j >> 2, mt = j & 3;
-                    constexpr int issued_next = j < n_next ? j : n_next; // one read of the next k-step per MFMA so far
+                    constexpr int issued_next = RPS * j < n_next ? RPS * j : n_next; // reads of the next k-step issued so far
                     if constexpr (mt == 0) {
-                        // reads of THIS k-step still allowed in flight: those after B_nt; plus all reads of the next one
-                        // issued so far.  (First k-step of a later chunk: its B came before the barrier, its A after ->
-                        // everything of this k-step must be in.)
-                        constexpr int after = (first_of_chunk && part > 0) ? 0 : NT - 1 - nt;
+                        // reads of THIS k-step still allowed in flight: those after (the last dword of) B_nt; plus all reads
+                        // of the next one issued so far.  (First k-step of a later chunk: its B came before the barrier, its
+                        // A after -> everything of this k-step must be in.)
+                        constexpr int after = (first_of_chunk && part > 0) ? 0 : (cur_gather ? 4 * (NT - 1 - nt) : NT - 1 - nt);
                         wait_lgkm(after + issued_next + n_ep);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (j < n_next) { // one read of the next k-step per MFMA, in the same order
-                        constexpr int r = more_here ? j : j + 4; // B-only prefetch skips the A slots
-                        if constexpr (r < 4) READ_A(a[nxt][r], r < 3 ? wbl : wbl3, (ksl + 1) * REC + r * 1024);
-                        else read_b(b[nxt][r - 4], std::integral_constant<int, ks_next>{}, std::integral_constant<int, r - 4>{});
+                    static_for<RPS>([&](auto rr_c) { // reads of the next k-step, in its read order
+                        constexpr int r0 = RPS * j + decltype(rr_c)::value;
+                        if constexpr (r0 < n_next) {
+                            constexpr int r = more_here ? r0 : r0 + 4; // a B-only prefetch skips the A slots
+                            if constexpr (r < 4) READ_A(a[nxt][r], r < 3 ? wbl : wbl3, (ksl + 1) * REC + r * 1024);
+                            else if constexpr (next_gather)
+                                read_bsp(bsp[(r - 4) / 4][(r - 4) % 4], std::integral_constant<int, (r - 4) % 4>{}, std::integral_constant<int, (r - 4) / 4>{});
+                            else read_b(b[nxt][r - 4], std::integral_constant<int, ks_next>{}, std::integral_constant<int, r - 4>{});
+                        }
+                    });
+                    if constexpr (cur_gather) {
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 u = {bsp[nt][0], bsp[nt][1], bsp[nt][2], bsp[nt][3]};
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], __builtin_bit_cast(half8, u), acc[mt][nt], 0, 0, 0);
+                    } else {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
                     }
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
@@ -412,9 +469,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             else epilogue(std::integral_constant<int, 2>{});
         }
     };
-    conv_step(0, std::integral_constant<int, 1>{}, std::integral_constant<int, AZ_NET_K0STEPS>{}, koff0, std::true_type{});
-    for (int conv = 1; conv < p.n_convs; conv++)
-        conv_step(conv, std::integral_constant<int, PARTS>{}, std::integral_constant<int, CK>{}, koff, std::false_type{});
+    conv_step(0, koff0, std::true_type{});
+    for (int conv = 1; conv < p.n_convs; conv++) conv_step(conv, koff, std::false_type{});
 }
 
 #ifdef AZ_EXPERIMENTAL_PP
@@ -1034,17 +1090,27 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     {   // device layout: [conv 0 compacted to AZ_NET_K0STEPS k-steps][conv 1 ..][..], one RECORD per k-step: output-channel
         // tiles 0..2 as in the ABI layout (3 KiB), tile 3 with only its stored rows (see WRec).  Conv 0 sees the input
         // planes only (channel octet 0), i.e. ABI groups 7*tap; they become groups 0..8 of its 4 k-steps.
+        // <= 50 filters: the K dimension is re-grouped into 15 k-steps (see dev_group below) - channels 48, 49 of the nine
+        // taps fit ONE k-step instead of filling the seventh channel octet of every tap.
         n->r3 = d.n_filters <= 50 ? 2 : 16;
+        const bool l15 = n->r3 < 16;
+        const int nks = l15 ? 15 : AZ_NET_KSTEPS;
         const int rows = n->r3 < 16 ? n->r3 + 1 : 16, rec = 3 * 1024 + 4 * rows * 16;
         const int n_convs = 2 * d.n_blocks;
         const size_t conv_b = (size_t)AZ_NET_KSTEPS * 4096;
-        std::vector<unsigned char> dev((size_t)(AZ_NET_K0STEPS + (size_t)(n_convs - 1) * AZ_NET_KSTEPS) * rec + 1024, 0);
+        std::vector<unsigned char> dev((size_t)(AZ_NET_K0STEPS + (size_t)(n_convs - 1) * nks) * rec + 8 * 4096 + 1024, 0); // + a chunk of padding
         const unsigned char *src = (const unsigned char *)d.conv_w;
         auto put_record = [&](unsigned char *dst, const unsigned char *ks4k) { // ks4k: [4 mt][64 lanes][16 B]
             memcpy(dst, ks4k, 3 * 1024);
             for (int q = 0; q < 4; q++)
                 for (int r = 0; r < (n->r3 < 16 ? n->r3 : 16); r++)
                     memcpy(dst + 3 * 1024 + (q * rows + r) * 16, ks4k + 3 * 1024 + (q * 16 + r) * 16, 16);
+        };
+        // ABI: element j of group g = tap * 7 + c8 is channel 8 * c8 + j at that tap.  abi_half: one fp16 of a conv
+        auto abi_half = [&](int c, int mt, int l15_, int tap, int ch) -> uint16_t {
+            int g = tap * 7 + (ch >> 3), oks = g >> 2, olane = (g & 3) * 16 + l15_;
+            const uint16_t *w = (const uint16_t *)(src + (size_t)c * conv_b);
+            return w[((((size_t)oks * 4 + mt) * 64 + olane) * 8) + (ch & 7)];
         };
         std::vector<unsigned char> c0(AZ_NET_K0STEPS * 4096, 0); // conv 0 compacted, still in 4 KiB k-steps
         for (int ks = 0; ks < AZ_NET_K0STEPS; ks++)
@@ -1057,8 +1123,32 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
                 }
         size_t off = 0;
         for (int ks = 0; ks < AZ_NET_K0STEPS; ks++, off += rec) put_record(&dev[off], &c0[(size_t)ks * 4096]);
+        std::vector<uint16_t> k4(4096 / 2);
         for (int c = 1; c < n_convs; c++)
-            for (int ks = 0; ks < AZ_NET_KSTEPS; ks++, off += rec) put_record(&dev[off], src + (size_t)c * conv_b + (size_t)ks * 4096);
+            for (int ks = 0; ks < nks; ks++, off += rec) {
+                if (!l15) {
+                    put_record(&dev[off], src + (size_t)c * conv_b + (size_t)ks * 4096);
+                    continue;
+                }
+                // 15-k-step grouping: group g' = 4 ks + q.  g' < 54: (tap, octet) = divmod(g', 6), the 48 channels of six
+                // full octets; g' = 54, 55: zero; k-step 14: element j of group q < 3 is channel 48 + (j & 1) at tap
+                // 4 q + j / 2 (taps > 8: zero), group 3 zero.
+                std::fill(k4.begin(), k4.end(), (uint16_t)0);
+                for (int mt = 0; mt < 4; mt++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int q = lane >> 4, l = lane & 15, gp = 4 * ks + q;
+                        uint16_t *o = &k4[(((size_t)mt * 64) + lane) * 8];
+                        for (int j = 0; j < 8; j++) {
+                            if (ks < 14) {
+                                if (gp < 54) o[j] = abi_half(c, mt, l, gp / 6, 8 * (gp % 6) + j);
+                            } else if (q < 3) {
+                                int tap = 4 * q + (j >> 1);
+                                if (tap < 9) o[j] = abi_half(c, mt, l, tap, 48 + (j & 1));
+                            }
+                        }
+                    }
+                put_record(&dev[off], (const unsigned char *)k4.data());
+            }
         up((void **)&n->conv_w, dev.data(), dev.size());
     }
     {   // [conv][3][64] (ABI) -> [conv][4][64] with the NEXT conv's bias in row 3 (what the kernel's ring slot holds)
@@ -1197,7 +1287,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         static const char *pp_env = getenv("AZ_TOWER_PP");
         const bool want_pp = pp_env ? atoi(pp_env) != 0 : false;
         TowerGeom gp = tower_geom(2, 4, n->d.rows, n->d.cols);
-        if (want_pp && gp.tpb == 3 && gp.ck == 8 && gp.lds <= 160 * 1024 && n_boards >= 2048) {
+        if (want_pp && n->r3 == 16 /* (it reads the 16-k-step stream) */ && gp.tpb == 3 && gp.ck == 8 && gp.lds <= 160 * 1024 && n_boards >= 2048) {
             tp.cells = gp.cells; tp.rs = gp.rs; tp.tpb = gp.tpb; tp.off_epi = gp.off_epi; tp.bpw = 2;
             tp.rcells = gp.rcells; tp.zcell = gp.zcell; tp.off_act = gp.off_act;
             int gridp = (n_boards + 7) / 8;

@@ -39,7 +39,8 @@ typedef struct az_net_desc {
     int32_t num_actions;    /* A; fc1 has A+1 outputs (network.py:45) */
     int32_t device;
     /* host pointers to the packed parameters (copied by az_net_create) */
-    const uint16_t *conv_w; /* fp16 bits [2*n_blocks][16 ksteps][4 mtiles][64 lanes][8] */
+    const uint16_t *conv_w; /* fp16 bits [2*n_blocks][16 ksteps][4 mtiles][64 lanes][8]: the interchange layout (group g = tap * 7 + channel
+                             * octet); az_net_create re-groups it for the device (conv 0: 4 k-steps; <= 50 filters: 15 k-steps) */
     const float *conv_epi;  /* [2*n_blocks][3][64]: bias, next-prologue scale, next-prologue shift */
     const float *in_affine; /* [2][8]: block-1 bn1 scale / shift for the input planes */
     const float *skip_w;    /* [64][4]: block-1 conv3 (1x1) weights, out-channel major, zero padded */
