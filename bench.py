@@ -261,8 +261,8 @@ def main():
     traffic_net = traffic_tree = None
     if (game.name, G, S, args.blocks, args.filters, args.net, args.weights) == ("connect_four", 4096, 400, 10, 50,
                                                                                 "fused", "random"):
-        traffic_net = 2 * (5493.5e3 + 11125.5e3) + 21635.2e3 + 128.0e3
-        traffic_tree = 4878.1e3 + 5802.8e3
+        traffic_net = 2 * (5257.5e3 + 11125.5e3) + 21547.2e3 + 128.0e3
+        traffic_tree = 4877.7e3 + 5802.6e3
 
     if rank == 0:
         plies_per_game = moves_all / max(1.0, games_all)
