@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--net", default="fused", choices=["fused", "torch"],
                     help="fused = csrc/az_net.hip MFMA tower (fp16 operands, fp32 accumulate); torch = nn.Module under PyTorch-ROCm")
     ap.add_argument("--dtype", default=None, choices=["f32", "f16", "bf16"], help="torch backend only (fused is f16)")
-    ap.add_argument("--check-every", type=int, default=32)
+    ap.add_argument("--check-every", type=int, default=128)
     ap.add_argument("--nodes-per-slot", type=int, default=0, help="node-pool capacity per slot (0 = engine default)")
     ap.add_argument("--max-sims-per-tick", type=int, default=0, help="NN-free playouts a slot may chain per tick (0 = default)")
     ap.add_argument("--chain-window-us", type=int, default=0, help="chained playouts only start this early in a launch (0 = default, <0 = off)")
