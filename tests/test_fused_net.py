@@ -108,6 +108,26 @@ def test_fused_forward_matches_torch(tag, n):
 
 
 @pytest.mark.gpu
+def test_fused_outputs_do_not_depend_on_the_batch_size():
+    """Different batch sizes run different kernel variants (8-wave / 4-wave workgroups, chunk sizes, 1-2 boards per wave):
+    a board's priors, value and tower output must be the same bits in all of them (the engine's slot-count invariance
+    rests on this)."""
+    game, net = _nets()["c4_10block"]
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=4096)
+    torch.manual_seed(5)
+    obs = (torch.rand(4096, 4, 6, 7, device="cuda") > 0.5).float()
+    ref_p, ref_v = [t.clone() for t in fn.forward(obs)]
+    torch.cuda.synchronize()
+    ref_t = fn.read_tower(4096)
+    for n in (2048, 1024, 300, 64, 5):
+        p, v = fn.forward(obs[:n].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(p, ref_p[:n]) and torch.equal(v, ref_v[:n]), n
+        assert (fn.read_tower(n) == ref_t[:n]).all(), n
+    fn.close()
+
+
+@pytest.mark.gpu
 def test_fused_net_rejects_bad_arguments():
     game, net = _nets()["c4_ckpt"]
     fn = fusednet.FusedNet(net, "cuda:0", max_boards=8)
