@@ -10,7 +10,8 @@ LIB_PATH = os.environ.get("AZ_ENGINE_LIB") or os.path.join(HERE, "libaz_engine.s
 GAME_CONNECT_FOUR, GAME_BREAKTHROUGH = 0, 1
 BACKUPS = {"on-policy": 0, "soft-Z": 1, "A0C": 2, "off-policy": 3}
 RNG_PHILOX, RNG_INJECTED = 0, 1
-FAULTS = {1: "POOL_EXHAUSTED", 2: "PLY_OVERFLOW", 4: "NO_VISITS", 8: "BAD_PRIOR"}
+FAULTS = {1: "POOL_EXHAUSTED", 2: "PLY_OVERFLOW", 4: "NO_VISITS", 8: "BAD_PRIOR", 16: "ILLEGAL_ACTION"}
+ACTION_NONE, ACTION_SEARCH_AGAIN = -1, -2
 
 
 class AzConfig(C.Structure):
@@ -65,7 +66,8 @@ class AzReplayConfig(C.Structure):
 
 
 class AzReplayStats(C.Structure):
-    _fields_ = [("n_games", C.c_int64), ("n_examples", C.c_int64), ("n_unique", C.c_int64), ("games_dropped", C.c_int64)]
+    _fields_ = [("n_games", C.c_int64), ("n_examples", C.c_int64), ("n_unique", C.c_int64), ("games_dropped", C.c_int64),
+                ("fault_flags", C.c_int64)]
 
 
 # every symbol include/az_engine.h, include/az_net.h and include/az_replay.h declare: (name, restype, argtypes)
@@ -107,6 +109,7 @@ PROTOTYPES = [
     ("az_replay_read_unique", C.c_int64, [_vp, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_int32)]),
+    ("az_replay_debug_set_key", C.c_int, [_vp, C.c_int64, C.c_uint64]),
     ("az_replay_read_example", C.c_int, [_vp, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]
 

@@ -794,12 +794,33 @@ __global__ __launch_bounds__(256) void az_update_root_kernel(Params p, const int
     if (g >= p.G) return;
     int action = rfl(actions[g]);
     int ph = rfl(p.phase[g]);
+    if (action == AZ_ACTION_SEARCH_AGAIN) { // MCTS.search() called again at an unchanged root (mcts.py:164-180): another
+                                            // S playouts on the same tree, root re-expanded with a fresh Dirichlet draw
+        if (ph == PH_SEARCH_DONE && lane == 0) {
+            p.sims[g] = 0;
+            p.phase[g] = p.use_dirichlet ? PH_NEED_ROOT : PH_RUN;
+        }
+        return;
+    }
     if (action < 0 || ph == PH_IDLE) return;
     SlotRegs sr;
     slot_load(p, g, sr);
     Pool t = pool_at(p, g, sr.half);
     unsigned int fault = 0;
     unsigned long long st_compact = 0;
+    { // the action must be legal in the root state (apply_action on an illegal move would corrupt the bitboards)
+        int k[3], act[3], mine;
+        enum_moves<GAME>(sr.rs, p.geom, lane, k, act, mine);
+        bool is_it = false;
+        for (int j = 0; j < mine; j++) is_it |= act[j] == action;
+        if (!__ballot(is_it)) {
+            if (lane == 0) {
+                p.phase[g] = PH_IDLE;
+                atomicOr(p.faults, AZ_FAULT_ILLEGAL_ACTION);
+            }
+            return;
+        }
+    }
     uint32_t c0 = rflu(t.nd[sr.root].C0);
     int nc = c0 == NONE32 ? 0 : (int)(rflu(t.nd[sr.root].META) >> 16);
     int cact = lane < nc ? (int)(t.nd[c0 + lane].META & 0xFFFFu) : -1;
@@ -951,6 +972,12 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     p.max_plies = az_max_plies(c.game, c.rows, c.cols);
     p.obs_elems = 4 * c.rows * c.cols;
     p.pstride = c.game == AZ_GAME_CONNECT_FOUR ? 64 : 192;
+    if (p.max_plies > p.pstride - 1) { // a select path holds one node per ply (Path<NP>: NP * 64 depths)
+        g_create_err = "board too large: a game may last " + std::to_string(p.max_plies) + " plies, the select path holds " +
+                       std::to_string(p.pstride - 1);
+        delete e;
+        return AZ_E_INVALID;
+    }
     p.G = c.n_slots;
     p.S = c.n_playouts;
     p.use_dirichlet = c.use_dirichlet ? 1 : 0;
@@ -1128,6 +1155,7 @@ extern "C" int az_engine_advance(az_engine *e, const float *priors, const float 
         e->err = "rng_mode INJECTED but az_engine_set_injected_rng was not called for all games";
         return AZ_E_STATE;
     }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((e->p.G + 3) / 4), block(256);
     bool pending = e->ticks > 0; // slots can only be waiting for the network after a first tick
@@ -1159,7 +1187,7 @@ extern "C" int az_engine_update_root(az_engine *e, const int32_t *actions, int32
     hipStream_t st = (hipStream_t)stream;
     if (!e->d_actions) HIPCHK(e, hipMalloc((void **)&e->d_actions, sizeof(int) * (size_t)e->p.G));
     for (int g = 0; g < e->p.G; g++)
-        if (actions[g] >= e->p.A) {
+        if (actions[g] >= e->p.A || actions[g] < AZ_ACTION_SEARCH_AGAIN) {
             e->err = "action out of range";
             return AZ_E_INVALID;
         }
@@ -1213,6 +1241,7 @@ extern "C" int az_engine_progress(az_engine *e, az_progress *out, void *stream) 
         if (faults & AZ_FAULT_PLY_OVERFLOW) e->err += " PLY_OVERFLOW";
         if (faults & AZ_FAULT_NO_VISITS) e->err += " NO_VISITS";
         if (faults & AZ_FAULT_BAD_PRIOR) e->err += " BAD_PRIOR";
+        if (faults & AZ_FAULT_ILLEGAL_ACTION) e->err += " ILLEGAL_ACTION";
         return AZ_E_DEVICE;
     }
     return AZ_OK;
@@ -1220,6 +1249,7 @@ extern "C" int az_engine_progress(az_engine *e, az_progress *out, void *stream) 
 
 extern "C" int az_engine_poll(az_engine *e, int64_t *games_done, uint32_t *error_flags, void *stream) {
     if (!e) return AZ_E_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     unsigned long long done = 0;
     unsigned int faults = 0;

@@ -38,6 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define OCT_B 16 // one cell of one channel-octet plane: 8 fp16
 #define AZ_NET_K0STEPS 4 // k-steps of conv 0 on the device (9 taps x the one octet holding the input planes, padded to 16 groups)
 #define N_OCT 7  // 56 channels
+#define AZ_MAX_DEVICES 64
 
 struct TowerParams {
     int H, W, HW, cells, cin, n_convs, n_boards, bpw;
@@ -473,353 +474,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
     for (int conv = 1; conv < p.n_convs; conv++) conv_step(conv, koff, std::false_type{});
 }
 
-#ifdef AZ_EXPERIMENTAL_PP
-// ------------------------------------------------------------------------------------------------
-// EXPERIMENTAL, not built by default (make ABL=-DAZ_EXPERIMENTAL_PP, then AZ_TOWER_PP=1 at run time).  Status at the end of
-// round 1: results bit-identical to az_tower_kernel; 237 us vs 211 us per 4096 boards (tools/net_microbench.py, same box).
-// 415 registers (256 VGPR + 159 AGPR), no scratch - but only after forcing every lambda inline and writing the conv loop
-// as straight-line pairs (with a kind dispatch inside the loop hipcc spilled loop-invariant tables to scratch: 323 us).
-// PMC (per wave): MFMA pipe busy 54 % of the wave's life, 23 % parked in s_waitcnt / barriers (with one wave per SIMD every
-// LDS-latency and barrier stall is exposed), 1.5 VALU instructions per MFMA against 1.0 in the 8-wave kernel (AGPR moves,
-// un-hoisted addresses), so the epilogue slices are VALU-issue bound.  Next: a third fragment buffer for the A operand
-// (needs ~16 registers back), store addresses in AGPRs instead of recomputed, parameter-free kind-0 epilogues.
-// "Ping-pong" tower: 4 waves per workgroup (one per SIMD), TWO boards per wave, same weight stream and barriers as the
-// 8-wave kernel above.  The two boards take turns on the matrix pipe, slice by slice (a slice = the k-steps of one
-// weight chunk for one board), and the epilogue of the board that has just finished a conv is cut into 2-instruction
-// micro-steps issued between the MFMAs of the other board's next slice:
-//     chunk (c,0):  [b0 MFMA | epilogue(b1, c-1)]  [b1 MFMA]          chunk (c,1):  [b0 MFMA]  [b1 MFMA | epilogue(b0, c)]
-// With two waves per SIMD running in lock step (they share every barrier) the epilogues of the 8-wave kernel are exposed
-// (ablation: -36 us without them); here the VALU work sits in the 12 idle issue cycles after every MFMA.
-// Arithmetic and its order are those of az_tower_kernel: same fragments, same k order per tile, same epilogue
-// expressions - a board's output does not depend on which kernel evaluated it.
-// Row-pair geometry only (W <= 7, 3 column tiles per board).
-// LDS operations the interleaved epilogue issues in step e: the tile's store in its last phase, and the parameter reads of
-// the next output-channel tile row in the first step of a row (kind 0/1/2 as in the kernel, -1 = no epilogue)
-__host__ __device__ constexpr int pp_epi_lds_ops(int kind, int e) {
-    int ph_n = kind == 0 ? 4 : (kind == 1 ? 6 : 3);
-    if (kind < 0 || e < 0 || e >= 12 * ph_n) return 0;
-    int tile = e / ph_n, ph = e % ph_n, mt = tile / 3, nt = tile % 3, n = 0;
-    if (kind != 2 && ph == ph_n - 1) n++;
-    if (nt == 0 && ph == 0 && mt < 3) n += kind == 1 ? 3 : 1;
-    return n;
-}
-// ... summed over the slots [s0, s1) of a slice of ckl k-steps (epilogue steps run in k-steps 1 .. ckl-2: slot s = step s-12)
-__host__ __device__ constexpr int pp_ops_between(int kind, int ckl, int s0, int s1) {
-    int n = 0;
-    for (int s = s0; s < s1; s++)
-        if (s >= 12 && s < (ckl - 1) * 12) n += pp_epi_lds_ops(kind, s - 12);
-    return n;
-}
-template <int CK, int R3>
-__global__ __launch_bounds__(256, 1) void az_tower_pp_kernel(TowerParams p) {
-    constexpr int NT = 3, WAVES = 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int REC = WRec<R3>::BYTES;
-    constexpr int CHUNK_B = CK * REC, CHUNK_S = CK * 4 * 64 * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = lane >> 4, l15 = lane & 15;
-    const int plane_b = p.rcells * OCT_B, region_b = N_OCT * plane_b;
-    const int board0 = (blockIdx.x * WAVES + wave) * 2; // first of this wave's two boards
-    const int region = p.off_act + wave * region_b;
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
-    const int trash = p.off_epi + 2048 + tid * 8;
-
-    {
-        uint4 z = {0, 0, 0, 0};
-        for (int i = lane * 16; i < region_b; i += 64 * 16) *(uint4 *)(lds + region + i) = z;
-    }
-    int pos_addr[2][NT], grow[2][NT];
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            int y = 2 * nt + (l15 >> 3), x = l15 & 7;
-            bool ok = x < p.W && y < p.H && board0 + b < p.n_boards;
-            int cell = b * p.cells + (y + 1) * p.rs + (x + 1);
-            pos_addr[b][nt] = region + cell * OCT_B; // padding lanes read their (finite) neighbours
-            grow[b][nt] = ok ? (board0 + b) * p.HW + y * p.W + x : -1;
-        }
-    const int bdelta = p.cells * OCT_B; // board 1's cells follow board 0's in every octet plane
-    int koff[AZ_NET_KSTEPS], koff0[AZ_NET_K0STEPS]; // full LDS address of board 0 / tile 0's fragment per k-step
-#pragma unroll
-    for (int ks = 0; ks < AZ_NET_KSTEPS; ks++) {
-        int g = 4 * ks + q;
-        int tap = g / 7, c8 = g - tap * 7;
-        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        koff[ks] = (g == 63 ? 0 : (dy * p.rs + dx) * OCT_B + c8 * plane_b) + (int)lds_base + pos_addr[0][0];
-    }
-#pragma unroll
-    for (int ks = 0; ks < AZ_NET_K0STEPS; ks++) {
-        int g = 4 * ks + q;
-        int dy = g / 3 - 1, dx = g - (g / 3) * 3 - 1;
-        koff0[ks] = (g < 9 ? (dy * p.rs + dx) * OCT_B : 0) + (int)lds_base + pos_addr[0][0];
-    }
-
-    f32x4 acc[2][4][NT], xres[2][4][NT];
-    {
-        f32x4 sw[4][4];
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) sw[mt][r] = *(const f32x4 *)(p.skip_w + (16 * mt + 4 * q + r) * 4);
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (grow[b][nt] >= 0) {
-                    int gb = grow[b][nt] / p.HW, pos = grow[b][nt] - gb * p.HW;
-#pragma unroll
-                    for (int c = 0; c < 4; c++)
-                        if (c < p.cin) v[c] = p.obs[((size_t)gb * p.cin + c) * p.HW + pos];
-                    if (q == 0) {
-                        half4 a4;
-#pragma unroll
-                        for (int c = 0; c < 4; c++) a4[c] = c < p.cin ? (_Float16)lrelu(p.in_scale[c] * v[c] + p.in_shift[c]) : (_Float16)0;
-                        *(half4 *)(lds + pos_addr[b][nt]) = a4;
-                    }
-                }
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++) {
-                    f32x4 x;
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        x[r] = sw[mt][r][0] * v[0] + sw[mt][r][1] * v[1] + sw[mt][r][2] * v[2] + sw[mt][r][3] * v[3];
-                    xres[b][mt][nt] = x;
-                    acc[b][mt][nt] = *(const f32x4 *)(p.epi + 16 * mt + 4 * q); // bias of conv 0
-                }
-            }
-    }
-
-    constexpr int PARTS = AZ_NET_KSTEPS / CK;
-    constexpr int C0_B = AZ_NET_K0STEPS * REC;
-    static_assert(CK % 2 == 0 && AZ_NET_K0STEPS % 2 == 0 && PARTS == 2, "slice schedule below is written for two chunks per conv");
-    static_assert(C0_B <= CHUNK_B && REC % 16 == 0 && ((CHUNK_B + 1023) & ~1023) <= CHUNK_S, "chunk must fit its LDS buffer");
-    const int n_chunks = 1 + (p.n_convs - 1) * PARTS;
-    auto issue_bytes = [&](const unsigned char *src, unsigned char *dst, auto bytes_c) {
-        constexpr int NPIECES = (decltype(bytes_c)::value + 1023) / 1024;
-#pragma unroll
-        for (int i = 0; i < (NPIECES + WAVES - 1) / WAVES; i++) {
-            int piece = i * WAVES + wave;
-            if (piece < NPIECES)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
-        }
-    };
-    auto issue_chunk = [&](int c) { // c >= 1
-        issue_bytes((const unsigned char *)p.conv_w + C0_B + (size_t)(c - 1) * CHUNK_B, lds + (c & 1) * CHUNK_S,
-                    std::integral_constant<int, CHUNK_B>{});
-    };
-    issue_bytes((const unsigned char *)p.conv_w, lds, std::integral_constant<int, C0_B>{});
-    if (wave == 0)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + lane * 16),
-                                         (__attribute__((address_space(3))) void *)(lds + p.off_epi), 16, 0, 0);
-
-    int chunk = 0;
-    half8 a[2][4], bf[2][NT];           // fragment double buffer, shared by the slices (k-step parity continues across them)
-    f32x4 ep_sc[2], ep_sh[2], ep_nb[2]; // epilogue parameters of output-channel tile mt (slot mt & 1), fetched one tile ahead
-    f32x4 tx[12];                       // per-tile temporaries of the epilogue in flight
-    half4 th[12], th2[12];
-
-    // ---- epilogue micro-steps -------------------------------------------------------------------------------------
-    // KIND 0: conv1 of a block (u = lrelu(acc)), 1: conv2 (x += acc; a = lrelu(sc*x + sh)), 2: last conv (x += acc -> HBM).
-    // Step e of board OB: tile = e / PH (mt-major), phase = e % PH; a couple of VALU instructions per phase.  The first step
-    // of output-channel tile mt also issues the (untracked) LDS reads of tile mt + 1's parameters.
-    auto ep_read_mt = [&](unsigned ep_base, auto mt_c, auto kind_c) __attribute__((always_inline)) { // 3 reads (kind 1) or 1 (kinds 0, 2: next bias only)
-        constexpr int mt = decltype(mt_c)::value, KIND = decltype(kind_c)::value;
-        if constexpr (KIND == 1) {
-            lds_read_f4_off<256 + mt * 64>(ep_sc[mt & 1], ep_base);
-            lds_read_f4_off<512 + mt * 64>(ep_sh[mt & 1], ep_base);
-        }
-        lds_read_f4_off<768 + mt * 64>(ep_nb[mt & 1], ep_base);
-    };
-    auto epi_micro = [&](auto kind_c, auto ob_c, auto e_c, unsigned ep_base) __attribute__((always_inline)) {
-        constexpr int KIND = decltype(kind_c)::value, OB = decltype(ob_c)::value, e = decltype(e_c)::value;
-        constexpr int PH = KIND == 0 ? 4 : (KIND == 1 ? 6 : 3);
-        if constexpr (e >= 0 && e < 12 * PH) {
-            constexpr int tile = e / PH, ph = e % PH, mt = tile / NT, nt = tile % NT;
-            const int co0 = 16 * mt + 4 * q;
-            if constexpr (nt == 0 && ph == 0 && mt < 3) ep_read_mt(ep_base, std::integral_constant<int, mt + 1>{}, kind_c);
-            if constexpr (KIND == 0) {
-                if constexpr (ph == 0) th[tile] = __builtin_convertvector(acc[OB][mt][nt], half4);
-                if constexpr (ph == 1) th2[tile] = th[tile] * (_Float16)0.01f;
-                if constexpr (ph == 2) th[tile] = __builtin_elementwise_max(th[tile], th2[tile]);
-            } else {
-                if constexpr (ph == 0) {
-                    tx[tile] = xres[OB][mt][nt] + acc[OB][mt][nt];
-                    xres[OB][mt][nt] = tx[tile];
-                }
-                if constexpr (KIND == 2) {
-                    if constexpr (ph == 1) th[tile] = __builtin_convertvector(tx[tile], half4);
-                    if constexpr (ph == 2)
-                        if (grow[OB][nt] >= 0) *(half4 *)(p.xout + (size_t)grow[OB][nt] * AZ_NET_XOUT_C + co0) = th[tile];
-                } else {
-                    if constexpr (ph == 1) tx[tile] = __builtin_elementwise_fma(ep_sc[mt & 1], tx[tile], ep_sh[mt & 1]);
-                    if constexpr (ph == 2) th[tile] = __builtin_convertvector(tx[tile], half4);
-                    if constexpr (ph == 3) th2[tile] = th[tile] * (_Float16)0.01f;
-                    if constexpr (ph == 4) th[tile] = __builtin_elementwise_max(th[tile], th2[tile]);
-                }
-            }
-            if constexpr (KIND != 2 && ph == PH - 1) { // the store to the activation planes + re-arm the accumulator
-                const bool wr = (2 * mt + (q >> 1)) < N_OCT;
-                const int woff = (2 * mt + (q >> 1)) * plane_b + (q & 1) * 8;
-                const int wa = opaque((wr && grow[OB][nt] >= 0) ? pos_addr[OB][nt] + woff : trash); // (not hoisted: 24 registers)
-                *(half4 *)(lds + wa) = th[tile];
-                acc[OB][mt][nt] = ep_nb[mt & 1];
-            }
-        }
-    };
-    auto ep_keep = [&]() {
-        keep_alive(ep_sc[0]);
-        keep_alive(ep_sc[1]);
-        keep_alive(ep_sh[0]);
-        keep_alive(ep_sh[1]);
-        keep_alive(ep_nb[0]);
-        keep_alive(ep_nb[1]);
-    };
-
-    // ---- one slice: CKL k-steps of board B on the chunk in buffer (chunk & 1) ------------------------------------------
-    // FOC: first slice on this chunk (barrier + DMA of the next chunk + A reads of k-step 0 here; its B fragments were
-    //      fetched by the previous slice, except for the very first slice).   NEXT: 0 nothing follows, 1 the next slice is
-    //      on the SAME chunk (prefetch A + B of its k-step 0), 2 on the NEXT chunk (prefetch B only).
-    // EK:  kind of the other board's epilogue interleaved here (-1 none); its steps run in k-steps 1 .. CKL-2 only: the
-    //      parameters read at the slice start have landed by then, and the last k-step's prefetch of the other board's
-    //      next B fragments comes after all of its stores.
-    auto slice = [&](auto b_c, auto ckl_c, auto kbase_c, const auto &kf, auto foc_c, auto next_c, auto nkb_c, const auto &nkf,
-                     auto ek_c, int conv, int conv_e, auto veryfirst_c) __attribute__((always_inline)) {
-        constexpr int B = decltype(b_c)::value, OB = 1 - B, CKL = decltype(ckl_c)::value, KBASE = decltype(kbase_c)::value;
-        constexpr bool FOC = decltype(foc_c)::value, VERYFIRST = decltype(veryfirst_c)::value;
-        constexpr int NEXT = decltype(next_c)::value, NKB = decltype(nkb_c)::value, EK = decltype(ek_c)::value;
-        constexpr int N_EP = EK < 0 ? 0 : (EK == 1 ? 3 : 1); // parameter reads of tile row 0, issued at the slice start
-        const unsigned kb = (unsigned)opaque(B ? bdelta : 0), nkb = (unsigned)opaque(OB ? bdelta : 0); // (the next slice is the other board's)
-        if constexpr (FOC) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (chunk + 1 < n_chunks) issue_chunk(chunk + 1);
-            if (KBASE == 0 && !VERYFIRST && wave == 0) // first chunk of conv `conv`: its epilogue parameters into the ring
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + (size_t)conv * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void *)(lds + p.off_epi + (conv & 1) * 1024), 16, 0, 0);
-        }
-        const unsigned wbl = lds_base + (chunk & 1) * CHUNK_S + lane * 16;
-        const unsigned wbl3 = R3 == 16 ? wbl
-                                       : lds_base + (chunk & 1) * CHUNK_S +
-                                             (q * WRec<R3>::ROWS + (l15 < WRec<R3>::ROWS - 1 ? l15 : WRec<R3>::ROWS - 1)) * 16;
-        const unsigned ep_base = lds_base + p.off_epi + (conv_e & 1) * 1024 + q * 16;
-        if constexpr (EK >= 0) ep_read_mt(ep_base, std::integral_constant<int, 0>{}, ek_c);
-        if constexpr (FOC) {
-            static_for<4>([&](auto mt_c) {
-                constexpr int mt = decltype(mt_c)::value;
-                READ_A(a[0][mt], mt < 3 ? wbl : wbl3, mt * 1024);
-            });
-            if constexpr (VERYFIRST)
-                static_for<NT>([&](auto nt_c) { READ_B_OFF(bf[0][decltype(nt_c)::value], (unsigned)kf[KBASE] + kb, decltype(nt_c)::value * 256); });
-        }
-        static_for<CKL>([&](auto ksl_c) {
-            constexpr int ksl = decltype(ksl_c)::value;
-            constexpr int cur = ksl & 1, nxt = cur ^ 1;
-            constexpr bool more_here = ksl + 1 < CKL;
-            constexpr int n_next = more_here ? NT + 4 : (NEXT == 1 ? NT + 4 : (NEXT == 2 ? NT : 0));
-            // base address of the B fragments fetched during this k-step (one VALU add; the three tiles use immediates)
-            unsigned nb_addr = 0;
-            if constexpr (more_here) nb_addr = (unsigned)kf[KBASE + ksl + 1] + kb;
-            else if constexpr (NEXT != 0) nb_addr = (unsigned)nkf[NKB] + nkb;
-            static_for<4 * NT>([&](auto j_c) {
-                constexpr int j = decltype(j_c)::value;
-                constexpr int nt = j >> 2, mt = j & 3;
-                constexpr int g = ksl * 12 + j;       // slot in the slice
-                constexpr int e = g - 12;             // epilogue step issued in this slot (k-steps 1 .. CKL-2 only)
-                constexpr bool epi_here = EK >= 0 && ksl >= 1 && ksl <= CKL - 2;
-                constexpr int RPS = 2; // fragment reads issued per MFMA slot: with one wave per SIMD nothing else hides LDS latency,
-                                       // so the next k-step's reads go out in the first slots of this one
-                constexpr int issued_next = RPS * j < n_next ? RPS * j : n_next;
-                if constexpr (mt == 0) {
-                    // LDS operations younger than the fragment B_nt of this k-step (issued in slot g0 = (ksl-1)*12 + (4+nt)/RPS
-                    // of this slice, or at the end of the previous slice / the slice start for k-step 0):
-                    //   the later fragments of this k-step, the next k-step's reads issued so far, the epilogue's LDS
-                    //   operations from slot g0 on, and for k-step 0 the first parameter reads.
-                    constexpr int after = (FOC && ksl == 0) ? 0 : NT - 1 - nt;
-                    constexpr int g0 = (ksl - 1) * 12 + (4 + nt) / RPS;
-                    constexpr int eops = ksl >= 1 ? pp_ops_between(EK, CKL, g0, g) : 0;
-                    constexpr int extra = (ksl == 0 && !FOC) ? N_EP : 0; // (FOC: the parameter reads precede the A reads)
-                    wait_lgkm(after + issued_next + eops + extra);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                static_for<RPS>([&](auto rr_c) {
-                    constexpr int r = RPS * j + decltype(rr_c)::value; // read index in the next k-step's order A0..A3, B0..B2
-                    if constexpr (r < n_next) {
-                        if constexpr (more_here) {
-                            if constexpr (r < 4) READ_A(a[nxt][r], r < 3 ? wbl : wbl3, (ksl + 1) * REC + r * 1024);
-                            else READ_B_OFF(bf[nxt][r - 4], nb_addr, (r - 4) * 256);
-                        } else if constexpr (NEXT == 1) { // the other board starts over on this chunk
-                            if constexpr (r < 4) READ_A(a[nxt][r], r < 3 ? wbl : wbl3, r * 1024);
-                            else READ_B_OFF(bf[nxt][r - 4], nb_addr, (r - 4) * 256);
-                        } else { // NEXT == 2: next chunk, B only (its A fragments are read after the barrier)
-                            READ_B_OFF(bf[nxt][r], nb_addr, r * 256);
-                        }
-                    }
-                });
-                if constexpr (epi_here) epi_micro(ek_c, std::integral_constant<int, OB>{}, std::integral_constant<int, e>{}, ep_base);
-                acc[B][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][mt], bf[cur][nt], acc[B][mt][nt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-        if constexpr (EK >= 0) ep_keep();
-    };
-    // a whole epilogue, not overlapped (board 0 after conv 0; the last board after the last conv)
-    auto epilogue_now = [&](auto kind_c, auto ob_c, int conv_e) __attribute__((always_inline)) {
-        constexpr int KIND = decltype(kind_c)::value;
-        const unsigned ep_base = lds_base + p.off_epi + (conv_e & 1) * 1024 + q * 16;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ep_read_mt(ep_base, std::integral_constant<int, 0>{}, kind_c);
-        static_for<12 * (KIND == 0 ? 4 : (KIND == 1 ? 6 : 3))>([&](auto e_c) {
-            constexpr int e = decltype(e_c)::value, PH = KIND == 0 ? 4 : (KIND == 1 ? 6 : 3);
-            if constexpr (e % (3 * PH) == 0) { // a new tile row: its parameters (read one row ahead) must have landed
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                ep_keep();
-            }
-            epi_micro(kind_c, ob_c, e_c, ep_base);
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ep_keep();
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using IM = std::integral_constant<int, -1>;
-    using IK0 = std::integral_constant<int, AZ_NET_K0STEPS>;
-    using ICK = std::integral_constant<int, CK>;
-    using T = std::true_type;
-    using F = std::false_type;
-
-    // conv 0 (4 k-steps, one chunk): b0, then its epilogue (not overlapped: once per launch), then b1
-    slice(I0{}, IK0{}, I0{}, koff0, T{}, I1{}, I0{}, koff0, IM{}, 0, 0, T{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // (the prefetched fragments of b1's first k-step are in registers: the epilogue's LDS traffic cannot disturb them)
-    epilogue_now(I0{}, I0{}, 0);
-    slice(I1{}, IK0{}, I0{}, koff0, F{}, I2{}, I0{}, koff, IM{}, 0, 0, F{});
-    chunk++;
-    // the convs after conv 0 come in pairs (conv2 of a block, conv1 of the next one): straight-line code, no kind dispatch
-    auto conv_slices = [&](int conv, auto ek_prev_c, auto ek_own_c, auto last_c) __attribute__((always_inline)) {
-        constexpr bool LAST = decltype(last_c)::value;
-        // chunk (conv, 0): b0 with the epilogue of b1's previous conv, then b1
-        slice(I0{}, ICK{}, I0{}, koff, T{}, I1{}, I0{}, koff, ek_prev_c, conv, conv - 1, F{});
-        slice(I1{}, ICK{}, I0{}, koff, F{}, I2{}, ICK{}, koff, IM{}, conv, 0, F{});
-        chunk++;
-        // chunk (conv, 1): b0, then b1 with the epilogue of b0's conv
-        slice(I0{}, ICK{}, ICK{}, koff, T{}, I1{}, ICK{}, koff, IM{}, conv, 0, F{});
-        if constexpr (LAST) slice(I1{}, ICK{}, ICK{}, koff, F{}, I0{}, I0{}, koff, ek_own_c, conv, conv, F{});
-        else slice(I1{}, ICK{}, ICK{}, koff, F{}, I2{}, I0{}, koff, ek_own_c, conv, conv, F{});
-        chunk++;
-    };
-    for (int conv = 1; conv + 2 < p.n_convs; conv += 2) {
-        conv_slices(conv, I0{}, I1{}, F{});     // conv2 of a block: previous epilogue kind 0, its own kind 1
-        conv_slices(conv + 1, I1{}, I0{}, F{}); // conv1 of the next block
-    }
-    conv_slices(p.n_convs - 1, I0{}, I2{}, T{}); // the last conv: its epilogue writes the tower output
-    epilogue_now(I2{}, I1{}, p.n_convs - 1);
-}
-
-#endif // AZ_EXPERIMENTAL_PP
 
 // ------------------------------------------------------------------------------------------------
 // fc1 + softmax + tanh (network.py:61-64).  One workgroup = 16 boards; the K = HW*64 reduction is split
@@ -1193,11 +847,12 @@ extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
 }
 
 template <int NT, int CK, int WAVES, bool RP1, int R3> static hipError_t launch_tower_r3(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
-    static bool attr_set[16] = {false};
-    if (!attr_set[n->d.device & 15]) {
+    static bool attr_set[AZ_MAX_DEVICES] = {false}; // the attribute is per (function, device)
+    const int dv = n->d.device;
+    if (dv < 0 || dv >= AZ_MAX_DEVICES || !attr_set[dv]) {
         hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT, CK, WAVES, RP1, R3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (s != hipSuccess) return s;
-        attr_set[n->d.device & 15] = true;
+        if (dv >= 0 && dv < AZ_MAX_DEVICES) attr_set[dv] = true;
     }
     hipLaunchKernelGGL((az_tower_kernel<NT, CK, WAVES, RP1, R3>), dim3(grid), dim3(WAVES * 64), lds, st, tp);
     return hipGetLastError();
@@ -1210,18 +865,6 @@ template <int NT, int CK, int WAVES> static hipError_t launch_tower(const az_net
     if (tp.tpb && tp.bpw == 1 && tp.rs == 8 && tp.tpb <= NT) return launch_tower_rp<NT, CK, WAVES, true>(n, tp, grid, lds, st);
     return launch_tower_rp<NT, CK, WAVES, false>(n, tp, grid, lds, st);
 }
-#ifdef AZ_EXPERIMENTAL_PP
-template <int R3> static hipError_t launch_tower_pp(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
-    static bool attr_set[16] = {false};
-    if (!attr_set[n->d.device & 15]) {
-        hipError_t s = hipFuncSetAttribute((const void *)az_tower_pp_kernel<8, R3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (s != hipSuccess) return s;
-        attr_set[n->d.device & 15] = true;
-    }
-    hipLaunchKernelGGL((az_tower_pp_kernel<8, R3>), dim3(grid), dim3(256), lds, st, tp);
-    return hipGetLastError();
-}
-#endif
 template <int NT> static hipError_t launch_tower_ck(const az_net *n, const TowerParams &tp, int grid, const TowerGeom &g, hipStream_t st) {
     if constexpr (NT <= 3) {
         if (g.waves == 8) return g.ck == 8 ? launch_tower<NT, 8, 8>(n, tp, grid, g.lds, st) : launch_tower<NT, 4, 8>(n, tp, grid, g.lds, st);
@@ -1235,6 +878,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         n->err = "n_boards exceeds az_net_reserve()";
         return AZ_E_STATE;
     }
+    NCHK(n, hipSetDevice(n->d.device)); // the launch must pair `stream` with the device the net lives on
     hipStream_t st = (hipStream_t)stream;
     // boards per wave: one workgroup (4 waves) per CU is resident, a launch runs in ceil(WGs / 256) rounds and a
     // round costs ~ (column tiles + fixed part): pick the bpw that minimises rounds x tiles for THIS batch size.
@@ -1282,27 +926,10 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     tp.xout = n->xout;
     int per_wg = g.waves * g.bpw, grid = (n_boards + per_wg - 1) / per_wg;
     hipError_t s;
-#ifdef AZ_EXPERIMENTAL_PP
-    {   // ping-pong kernel: 4 waves x 2 boards, for batches that fill the chip (row-pair boards with 3 tiles)
-        static const char *pp_env = getenv("AZ_TOWER_PP");
-        const bool want_pp = pp_env ? atoi(pp_env) != 0 : false;
-        TowerGeom gp = tower_geom(2, 4, n->d.rows, n->d.cols);
-        if (want_pp && n->r3 == 16 /* (it reads the 16-k-step stream) */ && gp.tpb == 3 && gp.ck == 8 && gp.lds <= 160 * 1024 && n_boards >= 2048) {
-            tp.cells = gp.cells; tp.rs = gp.rs; tp.tpb = gp.tpb; tp.off_epi = gp.off_epi; tp.bpw = 2;
-            tp.rcells = gp.rcells; tp.zcell = gp.zcell; tp.off_act = gp.off_act;
-            int gridp = (n_boards + 7) / 8;
-            s = n->r3 == 2 ? launch_tower_pp<2>(n, tp, gridp, gp.lds, st) : launch_tower_pp<16>(n, tp, gridp, gp.lds, st);
-            goto tower_done;
-        }
-    }
-#endif
     switch (g.nt < 3 ? 3 : g.nt) {
     case 3: s = launch_tower_ck<3>(n, tp, grid, g, st); break;
     default: s = launch_tower_ck<4>(n, tp, grid, g, st); break;
     }
-#ifdef AZ_EXPERIMENTAL_PP
-tower_done:
-#endif
     if (s != hipSuccess) {
         n->err = std::string("tower launch: ") + hipGetErrorString(s);
         return AZ_E_HIP;
@@ -1322,10 +949,11 @@ tower_done:
         hipLaunchKernelGGL(az_head_logits_kernel, dim3((n_boards + 15) / 16, (n->n_ot + OTG - 1) / OTG), dim3(256), 0, st, hp, n->logits);
         hipLaunchKernelGGL(az_head_softmax_kernel, dim3((n_boards + 15) / 16), dim3(256), 0, st, hp, (const float *)n->logits);
     } else {
-        static bool head_attr[16] = {false};
-        if (!head_attr[n->d.device & 15]) {
+        static bool head_attr[AZ_MAX_DEVICES] = {false};
+        const int dv = n->d.device;
+        if (dv < 0 || dv >= AZ_MAX_DEVICES || !head_attr[dv]) {
             NCHK(n, hipFuncSetAttribute((const void *)az_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            head_attr[n->d.device & 15] = true;
+            if (dv >= 0 && dv < AZ_MAX_DEVICES) head_attr[dv] = true;
         }
         hipLaunchKernelGGL(az_head_kernel, dim3((n_boards + 15) / 16), dim3(HEAD_NW * 64), n->lds_head, st, hp);
     }

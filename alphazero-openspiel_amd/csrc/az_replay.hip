@@ -33,7 +33,8 @@ struct az_replay {
     int64_t capacity_games = 0, dropped = 0, n_unique = 0;
     uint64_t sample_calls = 0;
     // device
-    uint64_t *key = nullptr, *bb0 = nullptr, *bb1 = nullptr;
+    uint64_t *key = nullptr, *key2 = nullptr, *bb0 = nullptr, *bb1 = nullptr; // key2: an independent second hash of the history
+    unsigned int *faults = nullptr;                                             // AZ_REPLAY_FAULT_* bits
     int32_t *ply = nullptr;
     double *z = nullptr, *pi = nullptr;
     int64_t *unique = nullptr; // [n_unique] logical indices of the first occurrences, ascending
@@ -58,6 +59,8 @@ extern "C" int az_replay_destroy(az_replay *r) {
     if (!r) return AZ_OK;
     (void)hipSetDevice(r->cfg.device);
     (void)hipFree(r->key);
+    (void)hipFree(r->key2);
+    (void)hipFree(r->faults);
     (void)hipFree(r->bb0);
     (void)hipFree(r->bb1);
     (void)hipFree(r->ply);
@@ -121,7 +124,9 @@ extern "C" int az_replay_create(const az_replay_config *cfg, az_replay **out) {
         return AZ_E_HIP;
     }
     size_t n = (size_t)r->cap;
-    bool ok = hipMalloc((void **)&r->key, n * 8) == hipSuccess && hipMalloc((void **)&r->bb0, n * 8) == hipSuccess &&
+    bool ok = hipMalloc((void **)&r->key, n * 8) == hipSuccess && hipMalloc((void **)&r->key2, n * 8) == hipSuccess &&
+              hipMalloc((void **)&r->faults, 4) == hipSuccess && hipMemset(r->faults, 0, 4) == hipSuccess &&
+              hipMalloc((void **)&r->bb0, n * 8) == hipSuccess &&
               hipMalloc((void **)&r->bb1, n * 8) == hipSuccess && hipMalloc((void **)&r->ply, n * 4) == hipSuccess &&
               hipMalloc((void **)&r->z, n * 8) == hipSuccess && hipMalloc((void **)&r->pi, n * 8 * (size_t)r->A) == hipSuccess &&
               hipMalloc((void **)&r->unique, n * 8) == hipSuccess;
@@ -146,6 +151,18 @@ extern "C" int az_replay_stats_get(az_replay *r, az_replay_stats *out) {
     out->n_examples = r->n;
     out->n_unique = r->n_unique;
     out->games_dropped = r->dropped;
+    out->fault_flags = 0;
+    unsigned int f = 0;
+    RCHK(r, hipSetDevice(r->cfg.device));
+    RCHK(r, hipDeviceSynchronize());
+    RCHK(r, hipMemcpy(&f, r->faults, 4, hipMemcpyDeviceToHost));
+    out->fault_flags = f;
+    if (f) {
+        r->err = "device fault flags set:";
+        if (f & AZ_REPLAY_FAULT_KEY_COLLISION) r->err += " KEY_COLLISION";
+        if (f & AZ_REPLAY_FAULT_BAD_INDEX) r->err += " BAD_INDEX";
+        return AZ_E_DEVICE;
+    }
     return AZ_OK;
 }
 
@@ -170,7 +187,7 @@ struct AppendArgs {
     int n_src_games, max_plies, maxc, start_ply, A, on_policy;
     long long cap, head;
     PwPlan pw;
-    uint64_t *key, *bb0, *bb1;
+    uint64_t *key, *key2, *bb0, *bb1;
     int32_t *ply;
     double *z, *pi;
 };
@@ -253,9 +270,15 @@ __global__ void replay_keys_kernel(AppendArgs a) {
     uint64_t h = mix64(0x243F6A8885A308D3ull, (uint64_t)a.start_ply);
     h = mix64(h, a.states[s0 * 2]);
     h = mix64(h, a.states[s0 * 2 + 1]); // start position (identical for all games of a run)
+    // second, independent chain (other seed, other per-step tweak): the reference keys on the EXACT information-state
+    // string (train.py:177); (key, key2) together are a 128-bit fingerprint of the history, and the segment pass
+    // raises AZ_REPLAY_FAULT_KEY_COLLISION if two members of one `key` segment differ in key2, ply or position
+    uint64_t h2 = mix64(0x13198A2E03707344ull ^ (uint64_t)a.start_ply, a.states[s0 * 2] + 0x9E3779B97F4A7C15ull * a.states[s0 * 2 + 1]);
     for (int i = 0; i < len; i++) {
         a.key[(a.head + first + i) % a.cap] = h;
+        a.key2[(a.head + first + i) % a.cap] = h2;
         h = mix64(h, (uint64_t)a.move[s0 + i]);
+        h2 = mix64(h2 ^ 0xA4093822299F31D0ull, ((uint64_t)a.move[s0 + i] << 20) | (uint64_t)(i + 1));
     }
 }
 
@@ -290,6 +313,7 @@ static int append_common(az_replay *r, AppendArgs &a, const std::vector<int32_t>
     a.A = r->A;
     a.pw = r->pw;
     a.key = r->key;
+    a.key2 = r->key2;
     a.bb0 = r->bb0;
     a.bb1 = r->bb1;
     a.ply = r->ply;
@@ -396,7 +420,8 @@ __global__ void seg_flags_kernel(const uint64_t *skey, long long n, unsigned cha
 }
 // one wave per segment: members sidx[seg_start[s] .. seg_start[s+1]) are in buffer order (stable sort)
 __global__ void seg_average_kernel(const long long *seg_start, long long n_seg, long long n, const long long *sidx, long long head,
-                                   long long cap, int A, double *pi, double *z, unsigned char *first_flag) {
+                                   long long cap, int A, double *pi, double *z, unsigned char *first_flag, const uint64_t *key2,
+                                   const uint64_t *bb0, const uint64_t *bb1, const int32_t *ply, unsigned int *faults) {
     long long s = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (s >= n_seg) return;
@@ -406,6 +431,14 @@ __global__ void seg_average_kernel(const long long *seg_start, long long n_seg, 
     long long cnt = j1 - j0;
     if (cnt == 1) return; // x / 1 == x: nothing to write
     long long pf = (head + first) % cap;
+    { // exact-key guard: every member must be the same history as the first (same fingerprint, ply and position)
+        bool bad = false;
+        for (long long j = j0 + 1 + lane; j < j1; j += 64) {
+            long long pm = (head + sidx[j]) % cap;
+            bad |= key2[pm] != key2[pf] || ply[pm] != ply[pf] || bb0[pm] != bb0[pf] || bb1[pm] != bb1[pf];
+        }
+        if (bad) atomicOr(faults, AZ_REPLAY_FAULT_KEY_COLLISION);
+    }
     for (int a = lane; a < A; a += 64) { // flattened_buffer_dict[key][2] = [sum(x) for x in zip(acc, item[2])]
         double acc = pi[(size_t)pf * A + a];
         for (long long j = j0 + 1; j < j1; j++) acc = acc + pi[(size_t)((head + sidx[j]) % cap) * A + a];
@@ -472,7 +505,7 @@ extern "C" int az_replay_dedupe(az_replay *r, void *stream) {
     DCHK(hipStreamSynchronize(st));
     DCHK(hipMemsetAsync(first_flag, 0, n, st));
     hipLaunchKernelGGL(seg_average_kernel, dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, st, seg_start, n_seg, n, i_out,
-                       (long long)r->head, (long long)r->cap, r->A, r->pi, r->z, first_flag);
+                       (long long)r->head, (long long)r->cap, r->A, r->pi, r->z, first_flag, r->key2, r->bb0, r->bb1, r->ply, r->faults);
     DCHK(hipcub::DeviceSelect::Flagged(nullptr, tb2, iota, first_flag, (long long *)r->unique, d_count, (int)n, st));
     if (tb2 > tb) {
         (void)hipFree(tmp);
@@ -481,13 +514,19 @@ extern "C" int az_replay_dedupe(az_replay *r, void *stream) {
     }
     DCHK(hipcub::DeviceSelect::Flagged(tmp, tb2, iota, first_flag, (long long *)r->unique, d_count, (int)n, st)); // dict order
     long long n_unique = 0;
+    unsigned int faults = 0;
     DCHK(hipMemcpyAsync(&n_unique, d_count, 8, hipMemcpyDeviceToHost, st));
+    DCHK(hipMemcpyAsync(&faults, r->faults, 4, hipMemcpyDeviceToHost, st));
     DCHK(hipStreamSynchronize(st));
     DCHK(hipGetLastError());
     cleanup();
 #undef DCHK
     if (n_unique != n_seg) {
         r->err = "internal: unique count mismatch";
+        return AZ_E_DEVICE;
+    }
+    if (faults & AZ_REPLAY_FAULT_KEY_COLLISION) {
+        r->err = "remove_duplicates: two different histories share a 64-bit key (they would have been averaged); not deduplicated";
         return AZ_E_DEVICE;
     }
     r->n_unique = n_unique;
@@ -505,6 +544,7 @@ struct SampleArgs {
     const int32_t *ply;
     const double *z, *pi;
     float *x, *pio, *zo;
+    unsigned int *faults;
 };
 __global__ void replay_sample_kernel(SampleArgs a) {
     int b = blockIdx.x;
@@ -514,7 +554,16 @@ __global__ void replay_sample_kernel(SampleArgs a) {
         uint64_t h = mix64(mix64(a.seed, a.call), (uint64_t)b);
         u = (long long)__umul64hi(h, (uint64_t)a.n_unique);
     }
-    if (u < 0 || u >= a.n_unique) u = 0;
+    if (u < 0 || u >= a.n_unique) { // an index outside the de-duplicated list: poison the row and raise a fault (reported
+                                     // by the next az_replay_stats_get) instead of silently substituting example 0
+        if (threadIdx.x == 0) {
+            atomicOr(a.faults, AZ_REPLAY_FAULT_BAD_INDEX);
+            a.zo[b] = __builtin_nanf("");
+        }
+        for (int i = threadIdx.x; i < a.planes_elems; i += blockDim.x) a.x[(size_t)b * a.planes_elems + i] = __builtin_nanf("");
+        for (int i = threadIdx.x; i < a.A; i += blockDim.x) a.pio[(size_t)b * a.A + i] = __builtin_nanf("");
+        return;
+    }
     long long phys = (a.head + a.unique[u]) % a.cap;
     AzState s;
     s.bb0 = a.bb0[phys];
@@ -555,6 +604,8 @@ extern "C" int az_replay_sample(az_replay *r, const int64_t *indices, int32_t ba
     a.x = x;
     a.pio = pi;
     a.zo = z;
+    a.faults = r->faults;
+    RCHK(r, hipSetDevice(r->cfg.device));
     hipLaunchKernelGGL(replay_sample_kernel, dim3(batch), dim3(128), 0, (hipStream_t)stream, a);
     RCHK(r, hipGetLastError());
     return AZ_OK;
@@ -582,6 +633,14 @@ extern "C" int64_t az_replay_read_unique(az_replay *r, int64_t max_n, uint64_t *
         if (ply) RCHK(r, hipMemcpy(ply + i, r->ply + phys, 4, hipMemcpyDeviceToHost));
     }
     return r->n_unique;
+}
+
+extern "C" int az_replay_debug_set_key(az_replay *r, int64_t index, uint64_t key) {
+    if (!r || index < 0 || index >= r->n) return AZ_E_INVALID;
+    RCHK(r, hipSetDevice(r->cfg.device));
+    RCHK(r, hipDeviceSynchronize());
+    RCHK(r, hipMemcpy(r->key + (r->head + index) % r->cap, &key, 8, hipMemcpyHostToDevice));
+    return AZ_OK;
 }
 
 extern "C" int az_replay_read_example(az_replay *r, int64_t index, double *pi, double *z) {

@@ -3,6 +3,7 @@
 PyTorch is plumbing here: it owns the observation / prior / value device tensors, the stream and the
 PV-net; the search, game dynamics and rollout loop are the HIP kernels in csrc/az_engine.hip.
 """
+import copy
 import ctypes as C
 
 import numpy as np
@@ -257,7 +258,8 @@ class DeviceEvaluator:
     dtype: torch.float32 (reference arithmetic) or torch.float16 / torch.bfloat16 autocast."""
 
     def __init__(self, net, device, dtype=torch.float32, channels_last=False):
-        self.net = net.to(device).eval()
+        # a private copy: the caller's module (a Trainer's current_net) keeps its device and its train/eval mode
+        self.net = copy.deepcopy(net).to(device).eval()
         self.device = torch.device(device)
         self.dtype = dtype
         self.channels_last = channels_last

@@ -184,12 +184,18 @@ def emulate_forward(packed, obs, round_fp16=True):
     return e / e.sum(1, keepdims=True), np.tanh(logits[:, A]), tower
 
 
+PRECISIONS = ("f16",)  # MFMA operand formats the library offers (az_net.h)
+
+
 class FusedNet:
     """Device handle: az_net_create / az_net_forward.  Call signature matches engine.DeviceEvaluator:
     evaluator(obs, priors_out, values_out)."""
 
-    def __init__(self, net, device, max_boards=4096):
+    def __init__(self, net, device, max_boards=4096, precision="f16"):
         from . import _lib
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (PRECISIONS,))
+        self.precision = precision
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":

@@ -15,6 +15,7 @@ policy_fn: a bound `Net.predict` / an nn.Module (evaluated on the device) or any
 import numpy as np
 import torch
 
+from . import _lib
 from .engine import DeviceEvaluator, SelfPlayEngine
 from .games import Game, State
 
@@ -137,6 +138,8 @@ class MCTS:
         self._ensure_engine(state)
         self._sync_root(state)
         e = self._engine
+        if e.read_slot(0)["phase"] == 5:  # search() again at an unchanged root: the reference runs another n_playouts on
+            e.update_root([_lib.ACTION_SEARCH_AGAIN])  # the same tree and re-expands the root with fresh noise (mcts.py:164-190)
         obs, pri, val = self._io
         ply = len(self._history)
         if self.use_dirichlet:  # the draw of mcts.py:187, from numpy's global stream

@@ -20,8 +20,10 @@ Extra objects on the JSON line:
                  evaluated leaf x leaves per tick / HIP-event time of the forward
   roofline_tree  the search kernels (HBM bound, latency-limited): SURVEY.md §8(d) bytes per sim with the
                  measured mean depth / children x sims per tick / HIP-event time of az_engine_advance
-  cpu_baseline   the C oracle (same algorithm, sequential playouts, batch-1 torch CPU net — what the
-                 reference does in-process) on 1 host thread over a bounded number of moves
+  cpu_baseline   the C oracle (same algorithm, sequential playouts, batch-1 torch CPU net — what a reference
+                 worker process does) playing FULL games on the host cores: all cores, one thread, and the C1 point
+  reference_precision  the same engine and workload evaluated by fp32 Net.forward (the reference's arithmetic,
+                 network.py:48-64) for a bounded wall time after the timed run: games/s, sims/s, ms per forward
 """
 import argparse
 import json
@@ -50,44 +52,90 @@ def tree_bytes_per_sim(d, a_sel, a_leaf, A, H, W, state_bytes=16, C=3):
     return d * (16 * a_sel + 4) + 16 * (d + 1) + 16 * a_leaf + 4 * (A + 1) + 2 * state_bytes + 4 * (C + 1) * H * W
 
 
-def cpu_baseline(game_name, S, n_blocks, n_filters, mean_evals_per_game, budget_s=15.0):
-    """The oracle (C restatement) with the same Net on the host, 1 thread, batch-1 per leaf."""
-    from oracle import binding as orc
-    from alphazero_openspiel_amd.games import Game
-    from alphazero_openspiel_amd.network import Net
+def host_cores():
+    """Cores this process may really use: the affinity mask, cut to the cgroup's CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
-    torch.set_num_threads(1)
-    g = Game(game_name)
-    A = g.num_distinct_actions()
-    shape = g.information_state_normalized_vector_shape()
-    torch.manual_seed(0)
-    net = Net(shape, A, n_blocks=n_blocks, n_filters=n_filters).eval()
 
-    def policy(board):
-        with torch.no_grad():
-            p, v = net(torch.from_numpy(board.reshape(1, 4, g.rows, g.cols)).float())
-        return p[0].double().numpy(), float(v)
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
-    b0 = np.zeros(4 * g.rows * g.cols)
-    policy(b0)
-    t = time.perf_counter()
-    for _ in range(20):
-        policy(b0)
-    t_eval = (time.perf_counter() - t) / 20
-    moves = int(max(1, min(12, budget_s / ((S + 1) * t_eval))))
-    t = time.perf_counter()
-    out = orc.play_game_self(policy, game_name, n_playouts=S, seed=1, max_moves=moves)
-    dt = time.perf_counter() - t
-    c = out["counters"]
-    evals_per_s = c["evals"] / dt
+
+def _cpu_leg(n_workers, games_each, game_name, S, n_blocks, n_filters, weight_seed, budget_s):
+    """n_workers fresh child processes (python -m oracle.cpu_selfplay), each playing FULL self-play games with the C oracle
+    + a batch-1 torch-CPU net on one thread; they start together after a READY/GO handshake.  -> aggregate dict."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, "-m", "oracle.cpu_selfplay", "--game", game_name, "--games", str(games_each), "--playouts", str(S),
+           "--blocks", str(n_blocks), "--filters", str(n_filters), "--weight-seed", str(weight_seed), "--handshake",
+           "--budget-s", str(budget_s)]
+    procs = [subprocess.Popen(cmd + ["--seed", str(100 + i)], cwd=ROOT, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                              text=True) for i in range(n_workers)]
+    try:
+        for pr in procs:
+            line = pr.stdout.readline()
+            if line.strip() != "READY":
+                raise RuntimeError("cpu_selfplay worker failed to start: %r" % line)
+        t_go = time.time()
+        for pr in procs:
+            pr.stdin.write("go\n")
+            pr.stdin.flush()
+        res = [json.loads(pr.stdout.readline()) for pr in procs]
+        for pr in procs:
+            pr.wait()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    wall = max(r["t_end"] for r in res) - t_go
+    games = sum(r["games"] for r in res)
+    sims = sum(r["sims"] for r in res)
+    evals = sum(r["evals"] for r in res)
+    plies = sum(r["plies"] for r in res)
+    return {"games_per_s": games / wall, "sims_per_s": sims / wall, "evals_per_s": evals / wall, "games": games, "plies": plies,
+            "seconds": wall, "workers": n_workers, "ms_per_eval_per_core": 1e3 * sum(r["seconds"] for r in res) / max(1, evals)}
+
+
+def cpu_baseline(game_name, S, n_blocks, n_filters, weight_seed, quick=False):
+    """the CPU restatement (oracle/az_oracle.c: same algorithm, strictly sequential playouts per tree, tree
+    reuse, root Dirichlet, one batch-1 Net.forward per leaf through torch on the CPU - what a reference worker process does)
+    on this box's host cores, FULL games: all cores (>= 64 games), one thread (8 games), and the C1 plumbing point
+    (connect_four, 25 sims/move, 2-block, one thread).  Runs BEFORE this process touches the GPU; children are separate
+    processes.  Every leg is bounded (a worker stops starting games after its budget; only whole games count)."""
+    cores = host_cores()
+    workers = max(1, min(cores, 64))
+    games_each = 1 if quick else max(1, -(-64 // workers))
+    many = _cpu_leg(workers, games_each, game_name, S, n_blocks, n_filters, weight_seed, budget_s=(10 if quick else 45))
+    one = _cpu_leg(1, 1 if quick else 8, game_name, S, n_blocks, n_filters, weight_seed, budget_s=(5 if quick else 50))
+    c1 = _cpu_leg(1, 2 if quick else 8, "connect_four", 25, 2, 50, weight_seed, budget_s=10)
     return {
-        "value": evals_per_s / mean_evals_per_game if mean_evals_per_game else None,
-        "unit": "games/s", "cores": 1, "kind": "port",
-        "sample": "oracle/az_oracle.c play_game_self, first %d moves of one game at %d sims/move (%d playouts, %d "
-                  "batch-1 torch-CPU net evals in %.1f s); games/s = CPU evals/s / the GPU run's mean net evals per game"
-                  % (len(out["actions"]), S, c["sims"], c["evals"], dt),
-        "sims_per_s": c["sims"] / dt, "evals_per_s": evals_per_s, "ms_per_eval": 1e3 * t_eval,
-        "host_cpus": os.cpu_count(),
+        "value": many["games_per_s"], "unit": "games/s", "cores": workers, "kind": "port",
+        "sample": "oracle/az_oracle.c play_game_self + batch-1 torch-CPU Net (1 thread per process): %d processes x FULL games, "
+                  "%d games / %d plies at %d sims/move in %.1f s" % (workers, many["games"], many["plies"], S, many["seconds"]),
+        "sims_per_s": many["sims_per_s"], "evals_per_s": many["evals_per_s"], "ms_per_eval_per_core": many["ms_per_eval_per_core"],
+        "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "usable_cores": cores,
+        "one_thread": {"value": one["games_per_s"], "sims_per_s": one["sims_per_s"], "games": one["games"],
+                       "plies": one["plies"], "seconds": one["seconds"], "ms_per_eval": one["ms_per_eval_per_core"]},
+        "c1_one_thread": {"workload": "connect_four, 25 sims/move, 2-block x 50, 1 CPU thread (BASELINE configs[0])",
+                          "value": c1["games_per_s"], "sims_per_s": c1["sims_per_s"], "games": c1["games"],
+                          "seconds": c1["seconds"]},
+        # BASELINE.md section 2 (build container, 8 cores, pygames stub): the real reference's multi-process path reached
+        # 0.106 games/s / 1.34 k sims/s at 400 sims (8 processes), 0.91 games/s at 25 sims (1 process, 5-block checkpoint)
+        "reference_calibration": {"where": "build container, 8 cores (BASELINE.md section 2)",
+                                  "reference_400sims_8proc_games_per_s": 0.106, "reference_25sims_1proc_games_per_s": 0.91},
     }
 
 
@@ -113,6 +161,10 @@ def main():
     ap.add_argument("--chain-window-us", type=int, default=0, help="chained playouts only start this early in a launch (0 = default, <0 = off)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="full", choices=["full", "quick", "off"],
+                    help="full = SURVEY 8(d): all cores >= 64 full games + 1 thread 8 games + C1 point (~1.5 min); quick = 1 game per leg")
+    ap.add_argument("--ref-seconds", type=float, default=20.0,
+                    help="wall-time cap of the reference-precision (fp32 Net.forward) leg that follows the timed run; 0 = skip")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse several ranks on one GPU)")
@@ -121,6 +173,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "off":
+        # host-core baseline first: child processes, before this process initialises the GPU
+        cpu = cpu_baseline(args.game, args.playouts, args.blocks, args.filters, args.seed, quick=args.cpu_baseline == "quick")
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(args.backend)
@@ -155,7 +211,7 @@ def main():
         tdtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
         evaluator = E.DeviceEvaluator(net, device, dtype=tdtype)
 
-    n_total = (Wm + K + 2) * G
+    n_total = (Wm + K + 3) * G
     eng = E.SelfPlayEngine(game, G, n_playouts=S, max_games=n_total, device=device, seed=args.seed + 7919 * rank,
                            nodes_per_slot=args.nodes_per_slot, max_sims_per_tick=args.max_sims_per_tick,
                            chain_window_us=args.chain_window_us)
@@ -250,7 +306,8 @@ def main():
     a_leaf = (p1["nodes_allocated"] - p0["nodes_allocated"]) / max(1, evals)
     b_sim = tree_bytes_per_sim(d_mean, a_sel, a_leaf, A, H, Wd)
     f_eval = net_flops_per_eval(H, Wd, A, args.blocks, args.filters)
-    net_tflops = G * f_eval / t_net / 1e12  # the forward runs over all G slots every tick
+    net_tflops = evals_tick * f_eval / t_net / 1e12  # evaluated leaves only: slots without a request hold stale boards
+    e2e_tflops = evals_all / world / dt_all * f_eval / 1e12  # per GPU, over the whole timed region (gaps + tick kernel included)
     tree_gbs = sims_tick * b_sim / t_tree / 1e9
     peak = MFMA_PEAK_TFLOPS[args.dtype]
 
@@ -263,6 +320,42 @@ def main():
                                                                                 "fused", "random"):
         traffic_net = 2 * (5257.5e3 + 11125.5e3) + 21547.2e3 + 128.0e3
         traffic_tree = 4877.7e3 + 5802.6e3
+
+    # ---- reference-precision leg: the SAME engine and workload, evaluated by fp32 Net.forward (network.py:48-64 under
+    # PyTorch-ROCm) instead of the fp16-operand fused tower, for a bounded wall time.  Games finished in the window count.
+    ref_prec = None
+    if world == 1 and args.net == "fused" and args.ref_seconds > 0:
+        ev32 = E.DeviceEvaluator(net, device, dtype=torch.float32)
+        for _ in range(2):  # MIOpen kernel selection / workspace allocation
+            eng.advance(pri, val, obs)
+            ev32(obs, pri, val)
+        torch.cuda.synchronize(device)
+        q0 = eng.progress()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tr0 = time.perf_counter()
+        n_ticks, fwd_ms = 0, []
+        while time.perf_counter() - tr0 < args.ref_seconds:
+            for _ in range(8):
+                eng.advance(pri, val, obs)
+                if n_ticks % 64 == 0:
+                    e0.record()
+                    ev32(obs, pri, val)
+                    e1.record()
+                    e1.synchronize()
+                    fwd_ms.append(e0.elapsed_time(e1))
+                else:
+                    ev32(obs, pri, val)
+                n_ticks += 1
+            torch.cuda.synchronize(device)
+        q1 = eng.progress()
+        dtr = time.perf_counter() - tr0
+        ref_prec = {"dtype": "f32", "evaluator": "Net.forward fp32 under PyTorch-ROCm (MIOpen), same engine / slots / net weights",
+                    "value": (q1["games_done"] - q0["games_done"]) / dtr, "unit": "games/s",
+                    "sims_per_s": (q1["sims"] - q0["sims"]) / dtr, "evals_per_s": (q1["evals"] - q0["evals"]) / dtr,
+                    "games_counted": q1["games_done"] - q0["games_done"], "ticks": n_ticks, "seconds": dtr,
+                    "ms_per_launch": float(np.median(fwd_ms)),
+                    "tflops": (q1["evals"] - q0["evals"]) / max(1, n_ticks) * f_eval / (float(np.median(fwd_ms)) * 1e-3) / 1e12,
+                    "peak_tflops": MFMA_PEAK_TFLOPS["f32"]}
 
     if rank == 0:
         plies_per_game = moves_all / max(1.0, games_all)
@@ -287,6 +380,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": ("az_tower_kernel + az_head_kernel" if args.net == "fused" else "torch Net.forward (MIOpen)")
                                    + ", %d boards/launch" % G,
                          "achieved": net_tflops, "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
+                         "frac_end_to_end": e2e_tflops / peak, "end_to_end_tflops": e2e_tflops,
                          "traffic": traffic_net, "traffic_unit": "bytes/launch (PMC, profiles/r1_hbm_traffic_pmc.txt)",
                          "flops_per_eval": f_eval, "ms_per_launch": 1e3 * t_net,
                          "batch_fill": evals_tick / G},
@@ -295,9 +389,10 @@ def main():
                               "frac": tree_gbs / HBM_PEAK_GBS, "traffic": traffic_tree, "bytes_per_sim": b_sim,
                               "sims_per_launch": sims_tick, "ms_per_launch": 1e3 * t_tree},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            evals_per_game = evals_all / max(1.0, games_all)
-            out["cpu_baseline"] = cpu_baseline(game.name, S, args.blocks, args.filters, evals_per_game)
+        if ref_prec is not None:
+            out["reference_precision"] = ref_prec
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     eng.close()
     if world > 1:

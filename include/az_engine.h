@@ -52,6 +52,10 @@ extern "C" {
 #define AZ_FAULT_PLY_OVERFLOW 2u   /* a game exceeded max_plies */
 #define AZ_FAULT_NO_VISITS 4u      /* root has no visited child at move time (S too small) */
 #define AZ_FAULT_BAD_PRIOR 8u      /* NaN prior/value fed to advance */
+#define AZ_FAULT_ILLEGAL_ACTION 16u /* az_engine_update_root was given an action that is illegal in the slot's root state */
+
+#define AZ_ACTION_NONE (-1)         /* az_engine_update_root: leave the slot alone */
+#define AZ_ACTION_SEARCH_AGAIN (-2) /* az_engine_update_root: search the same root again (MCTS.search called twice, mcts.py:164-180) */
 
 /*
  * Search/agent configuration.  Field ↔ reference keyword (all reach the
@@ -171,9 +175,12 @@ int az_engine_set_start_prefix(az_engine *e, const int32_t *actions, int32_t n);
 int az_engine_advance(az_engine *e, const float *priors, const float *values, float *obs_out, void *stream);
 
 /* MCTS.update_root(action) (mcts.py:192-203) for every slot, manual_moves engines only: applies
- * actions[g] (host array [G]; -1 = leave the slot alone) to the slot's root state, keeps the chosen
+ * actions[g] (host array [G]; AZ_ACTION_NONE = leave the slot alone) to the slot's root state, keeps the chosen
  * child's subtree (or starts a fresh tree when keep_subtree == 0 or the root is a leaf) and arms the
- * next search.  A slot whose game ends goes idle. */
+ * next search.  A slot whose game ends goes idle.  An action that is illegal in the root state raises
+ * AZ_FAULT_ILLEGAL_ACTION and idles the slot (the state is left untouched).  AZ_ACTION_SEARCH_AGAIN re-arms a finished
+ * search on the SAME root: the tree is kept, another n_playouts run, the root is re-expanded with a fresh Dirichlet
+ * draw - what calling MCTS.search(state) twice does in the reference (mcts.py:164-190). */
 int az_engine_update_root(az_engine *e, const int32_t *actions, int32_t keep_subtree, void *stream);
 
 /* Counters; synchronises `stream`. */

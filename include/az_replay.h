@@ -46,7 +46,11 @@ typedef struct az_replay_stats {
     int64_t n_games, n_examples; /* currently stored */
     int64_t n_unique;            /* after the last az_replay_dedupe (0 before) */
     int64_t games_dropped;       /* total FIFO evictions */
+    int64_t fault_flags;         /* AZ_REPLAY_FAULT_* raised on the device since create */
 } az_replay_stats;
+
+#define AZ_REPLAY_FAULT_KEY_COLLISION 1u /* remove_duplicates met two different histories with one 64-bit key */
+#define AZ_REPLAY_FAULT_BAD_INDEX 2u     /* az_replay_sample was given an index outside [0, n_unique) */
 
 int az_replay_create(const az_replay_config *cfg, az_replay **out);
 int az_replay_destroy(az_replay *r);
@@ -65,22 +69,30 @@ int az_replay_append_engine(az_replay *r, az_engine *e, void *stream);
 /* Append games given as host arrays in the layout of az_example_view (used by tests and by the multi-rank gather). */
 int az_replay_append_host(az_replay *r, const az_example_view *v, int32_t start_ply, void *stream);
 
-/* Trainer.remove_duplicates over the whole (flattened) buffer.  Synchronises `stream`. */
+/* Trainer.remove_duplicates over the whole (flattened) buffer.  Synchronises `stream`.  Records are grouped by the
+ * 64-bit history hash; every member of a group is then checked against the group's first record (a second, independent
+ * 64-bit hash of the history, the ply and the position): a mismatch - two different histories under one key, which the
+ * reference, keying on the exact information-state string (train.py:177), would keep apart - returns AZ_E_DEVICE. */
 int az_replay_dedupe(az_replay *r, void *stream);
 
 /* The sampling of net_step (train.py:108-120): gather `batch` examples of the de-duplicated list into
  * x [batch][4][H][W] float32, pi [batch][A] float32, z [batch] float32 (all device).  `indices` (device int64
  * [batch], values in [0, n_unique)) are the `np.random.randint(len(flattened_buffer), size=batch_size)` draw;
- * pass NULL to draw them on the device (Philox, stream (seed, call counter)). */
+ * pass NULL to draw them on the device (Philox, stream (seed, call counter)).  An index outside [0, n_unique) fills its
+ * row with NaN and raises AZ_REPLAY_FAULT_BAD_INDEX (asynchronous: reported by az_replay_stats_get). */
 int az_replay_sample(az_replay *r, const int64_t *indices, int32_t batch, uint64_t seed, float *x, float *pi,
                      float *z, void *stream);
 
+/* Counters and device fault flags; synchronises the device.  Returns AZ_E_DEVICE when a fault flag is set. */
 int az_replay_stats_get(az_replay *r, az_replay_stats *out);
 
 /* Debug/parity read-back of the de-duplicated list (host arrays; any may be NULL): key hash, pi [n][A] float64,
  * z float64, index of the record in the flattened buffer, its bitboards and ply.  Returns n_unique or <0. */
 int64_t az_replay_read_unique(az_replay *r, int64_t max_n, uint64_t *key, double *pi, double *z, int64_t *buffer_index,
                               uint64_t *bitboards, int32_t *ply);
+/* Test hook for the collision guard of az_replay_dedupe: overwrite the 64-bit grouping key of stored example `index`
+ * (its second hash, ply and position stay), so two different histories can be made to share a key. */
+int az_replay_debug_set_key(az_replay *r, int64_t index, uint64_t key);
 /* Read back one stored example of the flattened buffer (after write-back): pi [A], z. */
 int az_replay_read_example(az_replay *r, int64_t index, double *pi, double *z);
 

@@ -1,0 +1,126 @@
+"""Loud failure instead of silent corruption at the C-ABI edges, and MCTS.search called twice.
+
+* az_engine_update_root with an action that is illegal in the root state -> AZ_FAULT_ILLEGAL_ACTION, state untouched;
+* az_engine_create for a board whose games can outlast the select-path buffer -> AZ_E_INVALID;
+* az_replay_sample with an index outside the de-duplicated list -> NaN row + AZ_REPLAY_FAULT_BAD_INDEX;
+* az_replay_dedupe when two different histories share the 64-bit grouping key -> AZ_E_DEVICE (the reference keys on the
+  exact information-state string, train.py:177);
+* MCTS.search(state) twice on the same root runs another n_playouts on the same tree (mcts.py:164-180);
+* every launching entry point sets its device: engine + net created on device 0 still work after the caller's current
+  device handle was switched by another engine's create (one-GPU box: exercised with device 0 twice).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fakepolicy
+
+pytestmark = pytest.mark.gpu
+
+
+def test_update_root_rejects_an_illegal_action_without_touching_the_state():
+    from alphazero_openspiel_amd import engine as E
+    eng = E.SelfPlayEngine("connect_four", 2, n_playouts=4, manual_moves=True, use_dirichlet=False, device=0)
+    eng.set_start_prefix([3, 3, 3, 3, 3, 3])   # column 3 is full
+    eng.reset(2)
+    before = eng.read_slot(0)
+    eng.update_root([3, -1])
+    with pytest.raises(E.EngineError, match="ILLEGAL_ACTION"):
+        eng.progress()
+    after = eng.read_slot(0)
+    assert after["bb"] == before["bb"] and after["ply"] == before["ply"] and after["phase"] == 0
+    assert eng.read_slot(1)["phase"] != 0   # the other slot is unaffected
+    eng.close()
+    # breakthrough: a straight move onto an occupied cell / an action of the other side
+    eng = E.SelfPlayEngine("breakthrough(rows=6,columns=6)", 1, n_playouts=4, manual_moves=True, use_dirichlet=False, device=0)
+    eng.reset(1)
+    legal = eng.game.new_initial_state().legal_actions()
+    bad = next(a for a in range(eng.A) if a not in legal)
+    eng.update_root([bad])
+    with pytest.raises(E.EngineError, match="ILLEGAL_ACTION"):
+        eng.progress()
+    eng.close()
+
+
+def test_create_rejects_boards_whose_games_outlast_the_path_buffer():
+    from alphazero_openspiel_amd import engine as E
+    with pytest.raises(E.EngineError, match="plies"):
+        E.SelfPlayEngine("breakthrough(rows=16,columns=4)", 1, n_playouts=4, device=0)
+    E.SelfPlayEngine("breakthrough(rows=8,columns=8)", 1, n_playouts=4, device=0).close()
+
+
+def test_search_twice_on_the_same_root_adds_another_n_playouts():
+    from alphazero_openspiel_amd import games
+    from alphazero_openspiel_amd.mcts import MCTS
+    from alphazero_openspiel_amd.network import state_to_board
+    from oracle import binding as orc
+
+    game = games.load_game("connect_four")
+    pf = fakepolicy.make_policy_fn(state_to_board, [3, 6, 7], 7, 4)
+    m = MCTS(pf, 7, n_playouts=30, use_dirichlet=False)
+    s = game.new_initial_state()
+    pi1 = m.search(s)
+    assert m.root.N == 30
+    pi2 = m.search(s)
+    assert m.root.N == 60 and abs(sum(pi2) - 1) < 1e-12 and pi1 != pi2
+    # the oracle doing the same: two searches of 30 on one tree
+    o = orc.MCTS(lambda b: fakepolicy.fake_eval(b, 7, 4), "connect_four", n_playouts=30, use_dirichlet=False)
+    st = orc.State("connect_four")
+    o.search(st)
+    want = o.search(st)
+    assert list(pi2) == want.tolist()
+    rs = o.root_stats()
+    assert [c.N for c in m.root.children.values()] == rs["cN"] and [c.Q for c in m.root.children.values()] == rs["cQ"]
+
+
+def _small_replay():
+    from alphazero_openspiel_amd import engine as E, replay
+    from alphazero_openspiel_amd.network import Net
+    torch.manual_seed(1)
+    net = Net([3, 6, 7], 7, n_blocks=2, n_filters=16)
+    ev = E.DeviceEvaluator(net, "cuda:0")
+    eng = E.SelfPlayEngine("connect_four", 8, n_playouts=8, max_games=8, seed=3)
+    E.run_selfplay(eng, ev, 8)
+    rep = replay.DeviceReplay("connect_four", max_games=8, device=0)
+    rep.append_engine(eng)
+    eng.close()
+    return rep
+
+
+def test_replay_sample_flags_out_of_range_indices():
+    rep = _small_replay()
+    n = rep.dedupe()
+    x, pi, z = rep.sample(4, indices=[0, n, -1, n - 1])
+    assert torch.isnan(x[1]).all() and torch.isnan(pi[2]).all() and torch.isnan(z[1]) and torch.isnan(z[2])
+    assert not torch.isnan(x[0]).any() and not torch.isnan(x[3]).any()
+    with pytest.raises(RuntimeError, match="BAD_INDEX"):
+        rep.stats()
+    rep.close()
+
+
+def test_dedupe_refuses_to_merge_different_histories_that_share_a_key():
+    rep = _small_replay()
+    n = rep.dedupe()
+    u = rep.read_unique()
+    # give the second ply of game 0 (history "a0") the key of the empty history: the 64-bit group then holds two
+    # different histories; the exact-key guard (second hash + ply + position) must refuse
+    assert rep.lib.az_replay_debug_set_key(rep._h, 1, int(u["key"][0])) == 0
+    with pytest.raises(RuntimeError, match="different histories"):
+        rep.dedupe()
+    rep.close()
+    assert n > 1
+
+
+def test_engine_and_net_set_their_device_in_every_launching_call():
+    """One-GPU box: the calls must at least survive an explicit hipSetDevice round trip (the multi-GPU case is the same
+    code path with another ordinal)."""
+    from alphazero_openspiel_amd import engine as E, fusednet
+    from alphazero_openspiel_amd.network import Net
+    torch.manual_seed(0)
+    net = Net([3, 6, 7], 7, n_blocks=2, n_filters=50).eval()
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=8)
+    eng = E.SelfPlayEngine("connect_four", 8, n_playouts=8, max_games=8, seed=1, device=0)
+    prog = E.run_selfplay(eng, fn, 8, use_graph=False)
+    assert prog["games_done"] == 8 and prog["error_flags"] == 0
+    eng.close()
+    fn.close()
