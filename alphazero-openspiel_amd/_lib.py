@@ -81,10 +81,13 @@ PROTOTYPES = [
     ("az_engine_set_injected_rng", C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64]),
     ("az_engine_set_start_prefix", C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32]),
     ("az_engine_advance", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    ("az_engine_advance_slots", C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     ("az_engine_update_root", C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32, _vp]),
     ("az_engine_progress", C.c_int, [_vp, C.POINTER(AzProgress), _vp]),
     ("az_engine_poll", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_uint32), _vp]),
     ("az_engine_export", C.c_int, [_vp, C.POINTER(AzExampleView), _vp]),
+    ("az_engine_export_device_bytes", C.c_int64, [_vp]),
+    ("az_engine_export_device", C.c_int, [_vp, _vp, C.c_int64, _vp]),
     ("az_engine_read_root", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double)]),
@@ -103,6 +106,7 @@ PROTOTYPES = [
     ("az_replay_set_capacity", C.c_int, [_vp, C.c_int64]),
     ("az_replay_append_engine", C.c_int, [_vp, _vp, _vp]),
     ("az_replay_append_host", C.c_int, [_vp, C.POINTER(AzExampleView), C.c_int32, _vp]),
+    ("az_replay_append_device", C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _vp]),
     ("az_replay_dedupe", C.c_int, [_vp, _vp]),
     ("az_replay_sample", C.c_int, [_vp, _vp, C.c_int32, C.c_uint64, _vp, _vp, _vp, _vp]),
     ("az_replay_stats_get", C.c_int, [_vp, C.POINTER(AzReplayStats)]),

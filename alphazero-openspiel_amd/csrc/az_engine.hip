@@ -553,11 +553,11 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
 // ------------------------------------------------------------------------------------------------
 // The tick kernel.  Hot path: consume network results, then MCTS.playout until the network is needed again.
 template <int GAME, int NP>
-__global__ __launch_bounds__(256) void az_advance_kernel(Params p, const float *__restrict__ priors,
+__global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_first, const int g_end, const float *__restrict__ priors,
                                                          const float *__restrict__ values, float *__restrict__ obs_out) {
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= p.G) return;
+    const int g = g_first + blockIdx.x * 4 + (threadIdx.x >> 6); // this launch covers slots [g_first, g_end)
+    if (g >= g_end) return;
     // ---- 0. everything that is addressed by the slot index alone: ONE memory round trip ------------------------
     // (the kernel is a chain of dependent reads - PMC: waves parked in s_waitcnt 63 % of their life - so its duration
     //  is the number of round trips on the longest chain)
@@ -1145,7 +1145,20 @@ extern "C" int az_engine_set_start_prefix(az_engine *e, const int32_t *actions, 
     return AZ_OK;
 }
 
-extern "C" int az_engine_advance(az_engine *e, const float *priors, const float *values, float *obs_out, void *stream) {
+static int advance_range(az_engine *e, int g_first, int g_end, const float *priors, const float *values, float *obs_out, void *stream) {
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((g_end - g_first + 3) / 4), block(256);
+    if (e->cfg.game == AZ_GAME_CONNECT_FOUR) {
+        hipLaunchKernelGGL((az_advance_kernel<AZG_CONNECT_FOUR, 1>), grid, block, 0, st, e->p, g_first, g_end, priors, values, obs_out);
+    } else {
+        hipLaunchKernelGGL((az_advance_kernel<AZG_BREAKTHROUGH, 3>), grid, block, 0, st, e->p, g_first, g_end, priors, values, obs_out);
+    }
+    HIPCHK(e, hipGetLastError());
+    return AZ_OK;
+}
+
+static int advance_checks(az_engine *e, const float *obs_out) {
     if (!e || !obs_out) return AZ_E_INVALID;
     if (!e->reset_done) {
         e->err = "az_engine_advance before az_engine_reset";
@@ -1155,22 +1168,33 @@ extern "C" int az_engine_advance(az_engine *e, const float *priors, const float 
         e->err = "rng_mode INJECTED but az_engine_set_injected_rng was not called for all games";
         return AZ_E_STATE;
     }
-    HIPCHK(e, hipSetDevice(e->cfg.device));
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid((e->p.G + 3) / 4), block(256);
+    return AZ_OK;
+}
+
+extern "C" int az_engine_advance(az_engine *e, const float *priors, const float *values, float *obs_out, void *stream) {
+    int rc = advance_checks(e, obs_out);
+    if (rc != AZ_OK) return rc;
     bool pending = e->ticks > 0; // slots can only be waiting for the network after a first tick
     if (pending && (!priors || !values)) {
         e->err = "az_engine_advance: priors/values may be NULL only on the first tick after reset";
         return AZ_E_INVALID;
     }
-    if (e->cfg.game == AZ_GAME_CONNECT_FOUR) {
-        hipLaunchKernelGGL((az_advance_kernel<AZG_CONNECT_FOUR, 1>), grid, block, 0, st, e->p, priors, values, obs_out);
-    } else {
-        hipLaunchKernelGGL((az_advance_kernel<AZG_BREAKTHROUGH, 3>), grid, block, 0, st, e->p, priors, values, obs_out);
+    rc = advance_range(e, 0, e->p.G, priors, values, obs_out, stream);
+    if (rc == AZ_OK) e->ticks++;
+    return rc;
+}
+
+extern "C" int az_engine_advance_slots(az_engine *e, int32_t first_slot, int32_t n_slots, const float *priors, const float *values,
+                                       float *obs_out, void *stream) {
+    int rc = advance_checks(e, obs_out);
+    if (rc != AZ_OK) return rc;
+    if (first_slot < 0 || n_slots < 1 || first_slot + n_slots > e->p.G || !priors || !values) {
+        e->err = "az_engine_advance_slots: slot range outside [0, n_slots) or NULL priors/values";
+        return AZ_E_INVALID;
     }
-    HIPCHK(e, hipGetLastError());
-    e->ticks++;
-    return AZ_OK;
+    rc = advance_range(e, first_slot, first_slot + n_slots, priors, values, obs_out, stream);
+    if (rc == AZ_OK) e->ticks++;
+    return rc;
 }
 
 extern "C" int az_engine_update_root(az_engine *e, const int32_t *actions, int32_t keep_subtree, void *stream) {
@@ -1301,6 +1325,55 @@ extern "C" int az_engine_export(az_engine *e, az_example_view *out, void *stream
     out->child_action = e->h_child_action.data();
     out->child_visits = e->h_child_visits.data();
     out->value = e->h_value.data();
+    return AZ_OK;
+}
+
+// ---- device-resident export: the generation's records packed into ONE caller-owned device buffer ----------------------
+// layout (every array 16-byte aligned, n = games of the generation, mp = max_plies, mc = max_children):
+//   game_len i32[n] | game_ret0 f32[n] | states u64[n][mp][2] | move u16[n][mp] | n_children u8[n][mp] |
+//   child_action u16[n][mp][mc] | child_visits u32[n][mp][mc] | value f64[n][mp]
+static void export_offsets(size_t n, size_t mp, size_t mc, size_t off[9]) {
+    const size_t sizes[8] = {n * 4, n * 4, n * mp * 16, n * mp * 2, n * mp, n * mp * mc * 2, n * mp * mc * 4, n * mp * 8};
+    off[0] = 0;
+    for (int i = 0; i < 8; i++) off[i + 1] = off[i] + ((sizes[i] + 15) & ~(size_t)15);
+}
+
+__global__ void fill_on_policy_values_kernel(const int *len, const float *ret0, double *value, int n_games, int max_plies, int start_ply) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; // game_utils.py:200-204: z_i = returns()[0] * (-1)^i
+    int g = (int)(t / max_plies), i = (int)(t % max_plies);
+    if (g >= n_games || i >= len[g]) return;
+    double z = (double)ret0[g];
+    value[(size_t)g * max_plies + start_ply + i] = ((start_ply + i) & 1) ? -z : z;
+}
+
+extern "C" int64_t az_engine_export_device_bytes(const az_engine *e) {
+    if (!e) return AZ_E_INVALID;
+    size_t off[9];
+    export_offsets((size_t)e->n_games, (size_t)e->p.max_plies, (size_t)e->p.maxc, off);
+    return (int64_t)off[8];
+}
+
+extern "C" int az_engine_export_device(az_engine *e, void *dev_buf, int64_t bytes, void *stream) {
+    if (!e || !dev_buf) return AZ_E_INVALID;
+    size_t n = (size_t)e->n_games, mp = (size_t)e->p.max_plies, mc = (size_t)e->p.maxc, off[9];
+    export_offsets(n, mp, mc, off);
+    if (bytes < (int64_t)off[8]) {
+        e->err = "az_engine_export_device: buffer smaller than az_engine_export_device_bytes()";
+        return AZ_E_INVALID;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    if (e->cfg.backup == AZ_BACKUP_ON_POLICY) {
+        long long threads = (long long)n * (long long)mp;
+        hipLaunchKernelGGL(fill_on_policy_values_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, e->p.rec_len,
+                           e->p.rec_ret0, e->p.rec_value, (int)n, (int)mp, e->p.start.ply);
+        HIPCHK(e, hipGetLastError());
+    }
+    char *b = (char *)dev_buf;
+    const void *src[8] = {e->p.rec_len, e->p.rec_ret0, e->p.rec_states, e->p.rec_move, e->p.rec_nchild, e->p.rec_child_action,
+                          e->p.rec_child_visits, e->p.rec_value};
+    const size_t sizes[8] = {n * 4, n * 4, n * mp * 16, n * mp * 2, n * mp, n * mp * mc * 2, n * mp * mc * 4, n * mp * 8};
+    for (int i = 0; i < 8; i++) HIPCHK(e, hipMemcpyAsync(b + off[i], src[i], sizes[i], hipMemcpyDeviceToDevice, st));
     return AZ_OK;
 }
 

@@ -407,6 +407,36 @@ extern "C" int az_replay_append_host(az_replay *r, const az_example_view *v, int
     return append_common(r, a, lens, st);
 }
 
+extern "C" int az_replay_append_device(az_replay *r, const void *dev_buf, int64_t n_games, int32_t start_ply, void *stream) {
+    if (!r || !dev_buf || n_games < 1 || start_ply < 0) return AZ_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    RCHK(r, hipSetDevice(r->cfg.device));
+    size_t ng = (size_t)n_games, mp = (size_t)r->max_plies, mc = (size_t)r->maxc;
+    const size_t sizes[8] = {ng * 4, ng * 4, ng * mp * 16, ng * mp * 2, ng * mp, ng * mp * mc * 2, ng * mp * mc * 4, ng * mp * 8};
+    size_t off[9] = {0};
+    for (int i = 0; i < 8; i++) off[i + 1] = off[i] + ((sizes[i] + 15) & ~(size_t)15);
+    const char *b = (const char *)dev_buf;
+    AppendArgs a;
+    memset(&a, 0, sizeof a);
+    a.game_len = (const int *)(b + off[0]);
+    a.game_ret0 = (const float *)(b + off[1]);
+    a.states = (const uint64_t *)(b + off[2]);
+    a.move = (const uint16_t *)(b + off[3]);
+    a.nchild = (const uint8_t *)(b + off[4]);
+    a.child_action = (const uint16_t *)(b + off[5]);
+    a.child_visits = (const uint32_t *)(b + off[6]);
+    a.value = (const double *)(b + off[7]);
+    a.n_src_games = (int)ng;
+    a.max_plies = (int)mp;
+    a.maxc = (int)mc;
+    a.start_ply = start_ply;
+    a.on_policy = 0; // az_engine_export_device has filled the on-policy targets in
+    std::vector<int32_t> lens(ng);
+    RCHK(r, hipMemcpyAsync(lens.data(), a.game_len, ng * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    RCHK(r, hipStreamSynchronize(st));
+    return append_common(r, a, lens, st);
+}
+
 // ------------------------------------------------------------------------------------------------ dedupe
 __global__ void gather_keys_kernel(const uint64_t *key, long long head, long long cap, long long n, uint64_t *out, long long *idx) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

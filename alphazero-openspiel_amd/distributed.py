@@ -83,16 +83,40 @@ def all_gather_exports(payload, device=None):
     return [unpack_export(b[:s].cpu().numpy()) for b, s in zip(bufs, sizes)]
 
 
+def all_gather_device_exports(buf):
+    """The generation-end exchange on packed device exports (engine.export_device()): every rank contributes its buffer
+    (same size on every rank: same game, same games per rank), every rank receives all of them, rank order, as ONE tensor
+    of world * nbytes.  Backend nccl (= RCCL over xGMI): the buffers never leave HBM.  gloo (CPU rehearsal): staged through
+    host memory and returned on the input's device."""
+    if world_size() == 1:
+        return buf
+    if dist.get_backend() == "nccl":
+        out = torch.empty(world_size() * buf.numel(), dtype=torch.uint8, device=buf.device)
+        dist.all_gather_into_tensor(out, buf)
+        return out
+    host = buf.cpu()
+    out = torch.empty(world_size() * host.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(out, host)
+    return out.to(buf.device)
+
+
 def broadcast_net(net, src=0):
     """Weights + BN buffers from the training rank to every self-play rank at generation start
-    (replaces the deepcopy handed to each handle_gpu process, reference examplegenerator.py:121)."""
+    (replaces the deepcopy handed to each handle_gpu process, reference examplegenerator.py:121).  One flat fp32
+    buffer, one broadcast (RCCL when the backend is nccl: the module must then live on this rank's GPU)."""
     if world_size() == 1:
         return
-    flat = torch.cat([t.detach().reshape(-1).float() for t in list(net.parameters()) + list(net.buffers())])
-    dist.broadcast(flat, src)
+    tensors = list(net.parameters()) + list(net.buffers())
+    flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+    backend = dist.get_backend()
+    if backend == "nccl" and not flat.is_cuda:
+        raise RuntimeError("broadcast_net over nccl needs the module on the rank's GPU")
+    wire = flat.cpu() if (backend == "gloo" and flat.is_cuda) else flat  # gloo: CPU rehearsal of several ranks on one box
+    dist.broadcast(wire, src)
+    flat = wire.to(flat.device)
     off = 0
     with torch.no_grad():
-        for t in list(net.parameters()) + list(net.buffers()):
+        for t in tensors:
             n = t.numel()
             t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
             off += n

@@ -145,6 +145,13 @@ class SelfPlayEngine:
                                                self._ptr(values, (self.G,)),
                                                self._ptr(obs, (self.G,) + self.obs_shape), self._stream()))
 
+    def advance_slots(self, first_slot, n_slots, priors, values, obs):
+        """The tick of slots [first_slot, first_slot + n_slots) only, on the current stream; priors / values / obs are the
+        whole-engine tensors.  Disjoint slot groups may run concurrently on different streams (see run_selfplay(overlap=))."""
+        self._check(self.lib.az_engine_advance_slots(self._h, int(first_slot), int(n_slots),
+                                                     self._ptr(priors, (self.G, self.A)), self._ptr(values, (self.G,)),
+                                                     self._ptr(obs, (self.G,) + self.obs_shape), self._stream()))
+
     def update_root(self, actions, keep_subtree=True):
         arr = (C.c_int32 * self.G)(*[int(a) for a in actions])
         self._check(self.lib.az_engine_update_root(self._h, arr, int(bool(keep_subtree)), self._stream()))
@@ -210,6 +217,41 @@ class SelfPlayEngine:
             "value": arr(v.value, (n, mp), np.float64),
             "start_ply": len(self.start_history),
         }
+
+
+    def export_device(self):
+        """Finished games of the generation packed into one uint8 device tensor (layout: include/az_engine.h,
+        az_engine_export_device) - the payload of the generation-end all-gather and of DeviceReplay.append_device."""
+        nbytes = self._check(self.lib.az_engine_export_device_bytes(self._h))
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.az_engine_export_device(self._h, C.c_void_p(buf.data_ptr()), int(nbytes), self._stream()))
+        return buf
+
+
+def device_export_layout(n_games, max_plies, max_children):
+    """(name, dtype, shape, byte offset) of every array in the packed device export + total bytes."""
+    n, mp, mc = int(n_games), int(max_plies), int(max_children)
+    spec = (("game_len", np.int32, (n,)), ("game_ret0", np.float32, (n,)), ("states", np.uint64, (n, mp, 2)),
+            ("move", np.uint16, (n, mp)), ("n_children", np.uint8, (n, mp)), ("child_action", np.uint16, (n, mp, mc)),
+            ("child_visits", np.uint32, (n, mp, mc)), ("value", np.float64, (n, mp)))
+    out, off = [], 0
+    for name, dt, shape in spec:
+        out.append((name, dt, shape, off))
+        off += (int(np.prod(shape)) * np.dtype(dt).itemsize + 15) & ~15
+    return out, off
+
+
+def unpack_device_export(host_bytes, n_games, max_plies, max_children, start_ply=0):
+    """A host copy of a packed device export -> the dict engine.export() returns (arrays are views)."""
+    host_bytes = np.ascontiguousarray(host_bytes, dtype=np.uint8)
+    layout, total = device_export_layout(n_games, max_plies, max_children)
+    if host_bytes.size < total:
+        raise ValueError("export buffer holds %d bytes, layout needs %d" % (host_bytes.size, total))
+    ex = {"start_ply": int(start_ply)}
+    for name, dt, shape, off in layout:
+        cnt = int(np.prod(shape)) * np.dtype(dt).itemsize
+        ex[name] = host_bytes[off:off + cnt].view(dt).reshape(shape)
+    return ex
 
 
 # ---------------------------------------------------------------------- host logic on engine records
@@ -301,10 +343,29 @@ class HostPolicyEvaluator:
         values_out.copy_(torch.from_numpy(val))
 
 
+def slot_groups(n_slots, k):
+    """Split [0, n_slots) into k contiguous groups whose sizes are multiples of 8 (a tower workgroup evaluates 8 boards)."""
+    per = -(-n_slots // max(1, int(k)))
+    per = -(-per // 8) * 8
+    groups, first = [], 0
+    while first < n_slots:
+        groups.append((first, min(per, n_slots - first)))
+        first += per
+    return groups
+
+
 def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_ticks=None, use_graph=False,
-                 on_tick=None):
+                 on_tick=None, overlap=1):
     """ExampleGenerator.run_games without processes: tick the engine until n_games are finished.
-    Returns the final progress dict."""
+    Returns the final progress dict.
+
+    overlap = k > 1 (BASELINE.json configs[4]: "overlapped PV-eval / tree-search HIP streams"): the slots are split into k
+    groups, each with its own HIP stream (and graph) ticking [az_engine_advance_slots, PV-net forward of the group]; a
+    group's tree search and launch gaps then run beside another group's forward.  `evaluator` must then be a list of k
+    evaluators, one per group (a FusedNet owns its intermediate buffers).  The games do not depend on the grouping:
+    random streams are keyed by game id."""
+    if overlap > 1:
+        return _run_selfplay_overlapped(engine, evaluator, n_games, seed, check_every, max_ticks, use_graph, overlap)
     engine.reset(n_games, seed)
     obs, pri, val = engine.alloc_io()
     ticks = 0
@@ -341,4 +402,70 @@ def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_tick
             raise EngineError("self-play did not finish within %d ticks: %r" % (max_ticks, engine.progress()))
     prog = engine.progress()
     prog["ticks"] = ticks
+    return prog
+
+
+class OverlappedTicker:
+    """k slot groups of one engine, each ticking on its own HIP stream (optionally as a captured graph)."""
+
+    def __init__(self, engine, evaluators, overlap, use_graph=True, io=None):
+        self.engine = engine
+        self.groups = slot_groups(engine.G, overlap)
+        if not isinstance(evaluators, (list, tuple)) or len(evaluators) != len(self.groups):
+            raise ValueError("overlap=%d needs a list of %d evaluators (one per slot group), got %r"
+                             % (overlap, len(self.groups), type(evaluators)))
+        self.evaluators = list(evaluators)
+        self.obs, self.pri, self.val = io if io is not None else engine.alloc_io()
+        dev = engine.device
+        self.streams = [torch.cuda.Stream(dev) for _ in self.groups]
+        self.graphs = []
+        torch.cuda.synchronize(dev)
+        main = torch.cuda.current_stream(dev)
+        for i, st in enumerate(self.streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                for _ in range(2):  # warm-up outside capture
+                    self._tick(i)
+            st.synchronize()
+            if use_graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    self._tick(i)
+                self.graphs.append(g)
+        self.ticks = 2
+
+    def _tick(self, i):
+        first, n = self.groups[i]
+        self.engine.advance_slots(first, n, self.pri, self.val, self.obs)
+        self.evaluators[i](self.obs[first:first + n], self.pri[first:first + n], self.val[first:first + n])
+
+    def tick(self):
+        """One tick of every group (enqueued group after group; the streams run them concurrently)."""
+        for i, st in enumerate(self.streams):
+            with torch.cuda.stream(st):
+                if self.graphs:
+                    self.graphs[i].replay()
+                else:
+                    self._tick(i)
+        self.ticks += 1
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+
+def _run_selfplay_overlapped(engine, evaluators, n_games, seed, check_every, max_ticks, use_graph, overlap):
+    engine.reset(n_games, seed)
+    torch.cuda.current_stream(engine.device).synchronize()
+    tk = OverlappedTicker(engine, evaluators, overlap, use_graph=use_graph)
+    while True:
+        for _ in range(check_every):
+            tk.tick()
+        tk.synchronize()
+        if engine.games_done() >= n_games:
+            break
+        if max_ticks is not None and tk.ticks >= max_ticks:
+            raise EngineError("self-play did not finish within %d ticks: %r" % (max_ticks, engine.progress()))
+    prog = engine.progress()
+    prog["ticks"] = tk.ticks
     return prog

@@ -80,6 +80,18 @@ class DeviceReplay:
         v.value = keep["value"].ctypes.data_as(C.POINTER(C.c_double))
         self._check(self.lib.az_replay_append_host(self._h, C.byref(v), int(ex.get("start_ply", 0)), self._stream()))
 
+    def append_device(self, buf, n_games, start_ply=0):
+        """Games from a packed DEVICE export (engine.export_device(), or one rank's section of the all-gathered buffer):
+        engine -> RCCL all-gather -> replay store with no host copy of the records."""
+        if buf.dtype != torch.uint8 or not buf.is_contiguous() or buf.device != self.device:
+            raise RuntimeError("append_device expects a contiguous uint8 tensor on %s" % (self.device,))
+        from .engine import device_export_layout
+        need = device_export_layout(n_games, self.game.max_game_length(), self.game.max_children())[1]
+        if buf.numel() < need:
+            raise RuntimeError("export buffer holds %d bytes, %d games need %d" % (buf.numel(), n_games, need))
+        self._check(self.lib.az_replay_append_device(self._h, C.c_void_p(buf.data_ptr()), int(n_games), int(start_ply),
+                                                     self._stream()))
+
     def dedupe(self):
         """Trainer.remove_duplicates over the flattened buffer; returns the number of unique examples."""
         self._check(self.lib.az_replay_dedupe(self._h, self._stream()))

@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--nodes-per-slot", type=int, default=0, help="node-pool capacity per slot (0 = engine default)")
     ap.add_argument("--max-sims-per-tick", type=int, default=0, help="NN-free playouts a slot may chain per tick (0 = default)")
     ap.add_argument("--chain-window-us", type=int, default=0, help="chained playouts only start this early in a launch (0 = default, <0 = off)")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="slot groups ticking on their own HIP streams (BASELINE configs[4]: overlapped PV-eval / tree-search "
+                         "streams): a group's tree search and launch gaps run beside another group's forward")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "quick", "off"],
@@ -202,6 +205,9 @@ def main():
         args.blocks, args.filters = net.n_blocks, net.n_filts
     else:
         net = Net(game.information_state_normalized_vector_shape(), A, n_blocks=args.blocks, n_filters=args.filters)
+    if world > 1:  # the path's first collective: every rank takes the training rank's weights (examplegenerator.py:121)
+        net = net.to(device)
+        azdist.broadcast_net(net, src=0)
     if args.net == "fused":
         from alphazero_openspiel_amd.fusednet import FusedNet
         args.dtype = "f16"
@@ -235,6 +241,13 @@ def main():
         with torch.cuda.graph(graph):
             tick_eager()
     tick = graph.replay if graph is not None else tick_eager
+    sync_groups = lambda: None
+    if args.overlap > 1:  # k slot groups, each [advance_slots, forward] on its own stream / graph
+        if args.net != "fused":
+            raise SystemExit("--overlap needs --net fused")
+        group_nets = [FusedNet(net.eval(), device, max_boards=n) for _, n in E.slot_groups(G, args.overlap)]
+        tk = E.OverlappedTicker(eng, group_nets, args.overlap, use_graph=not args.no_graph, io=(obs, pri, val))
+        tick, sync_groups, graph = tk.tick, tk.synchronize, (tk.graphs or None)
 
     def barrier():
         if world > 1:
@@ -246,6 +259,7 @@ def main():
             for _ in range(args.check_every):
                 tick()
             ticks += args.check_every
+            sync_groups()
             if eng.games_done() >= n_done:
                 return eng.progress(), ticks
 
@@ -255,6 +269,7 @@ def main():
     else:
         for _ in range(args.check_every):
             tick()
+        sync_groups()
         p0 = eng.progress()
     barrier()
     torch.cuda.synchronize(device)
@@ -264,9 +279,10 @@ def main():
     t_ag0 = time.perf_counter()
     allgather_ms = None
     if world > 1:  # generation-end exchange of the finished-game records (the path's only collective)
-        packed = azdist.pack_export(eng.export())
-        exports = azdist.all_gather_exports(packed, device)
-        assert len(exports) == world
+        buf = eng.export_device()  # packed records, device resident
+        gathered = azdist.all_gather_device_exports(buf)  # RCCL all-gather over xGMI (nccl backend)
+        torch.cuda.synchronize(device)
+        assert gathered.numel() == world * buf.numel()
         allgather_ms = 1e3 * (time.perf_counter() - t_ag0)
     torch.cuda.synchronize(device)
     barrier()
@@ -364,8 +380,10 @@ def main():
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1e3 * dt_all / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s, %d sims/move, %d-block x %d-filter ResNet, %d concurrent games per GPU"
-                                   % (game.name, S, args.blocks, args.filters, G),
+            "config": {"workload": "%s, %d sims/move, %d-block x %d-filter ResNet, %d concurrent games per GPU%s"
+                                   % (game.name, S, args.blocks, args.filters, G,
+                                      "" if args.overlap < 2 else " in %d slot groups on %d HIP streams" % (args.overlap, args.overlap)),
+                       "overlap": args.overlap,
                        "weights": ("random-init (torch.manual_seed), eval-mode BN" if args.weights == "random" else
                                    "the reference's shipped checkpoint (5-block x 50)"), "net_backend": args.net,
                        "tree_dtype": "f64", "c_puct": 2.5, "temperature": 1.0, "dirichlet_alpha": 0.3,

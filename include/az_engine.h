@@ -174,6 +174,18 @@ int az_engine_set_start_prefix(az_engine *e, const int32_t *actions, int32_t n);
  */
 int az_engine_advance(az_engine *e, const float *priors, const float *values, float *obs_out, void *stream);
 
+/* The same tick for the slots [first_slot, first_slot + n_slots) only.  priors / values / obs_out are still the
+ * WHOLE-engine arrays ([G][A], [G], [G][C+1][H][W]); the launch reads and writes the rows of its slots.  Slot groups
+ * are independent (they share only the game-id counter, by device atomics), so disjoint groups may be advanced
+ * concurrently on DIFFERENT streams: while one group's PV-net forward runs, another group's tree search runs beside it
+ * (BASELINE.json configs[4]: "overlapped PV-eval / tree-search HIP streams"; the reference's analogue is its pool of
+ * worker processes running beside the inference server, examplegenerator.py:106-138).  Which group plays which game
+ * does not change a game: random streams are keyed by game id.  az_engine_progress / poll / export synchronise only the
+ * stream they are given: synchronise the other group streams first.  priors/values must not be NULL here (give
+ * initialised buffers on the first tick: slots without an outstanding request ignore them). */
+int az_engine_advance_slots(az_engine *e, int32_t first_slot, int32_t n_slots, const float *priors, const float *values,
+                            float *obs_out, void *stream);
+
 /* MCTS.update_root(action) (mcts.py:192-203) for every slot, manual_moves engines only: applies
  * actions[g] (host array [G]; AZ_ACTION_NONE = leave the slot alone) to the slot's root state, keeps the chosen
  * child's subtree (or starts a fresh tree when keep_subtree == 0 or the root is a leaf) and arms the
@@ -192,6 +204,17 @@ int az_engine_poll(az_engine *e, int64_t *games_done, uint32_t *error_flags, voi
 
 /* Copy finished games to host memory owned by the engine; synchronises `stream`. */
 int az_engine_export(az_engine *e, az_example_view *out, void *stream);
+
+/* The same records, device to device: the finished games of the generation packed into ONE caller-owned device buffer
+ * (asynchronous on `stream`), ready for the generation-end collective (RCCL all-gather over xGMI) and for
+ * az_replay_append_device on the receiving side - the replacement of the pickled `pool.map_async(...).get()` gather of
+ * examplegenerator.py:151-152 without a host round trip.  Layout, n = games of the generation (the n_games given to
+ * az_engine_reset), mp = max_plies, mc = max_children, every array 16-byte aligned, in this order:
+ *   game_len i32[n] | game_ret0 f32[n] | states u64[n][mp][2] | move u16[n][mp] | n_children u8[n][mp] |
+ *   child_action u16[n][mp][mc] | child_visits u32[n][mp][mc] | value f64[n][mp]
+ * (the arrays of az_example_view; on-policy value targets are filled in on the device). */
+int64_t az_engine_export_device_bytes(const az_engine *e);
+int az_engine_export_device(az_engine *e, void *dev_buf, int64_t bytes, void *stream);
 
 /* debug / parity read-back of one slot's root (mcts.root.{N,Q,children[a].{N,Q,P}}, read by
  * game_utils.py:30-31,174,178,183-193).  Arrays sized max_children.  Returns n_children or <0.

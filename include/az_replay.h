@@ -69,6 +69,11 @@ int az_replay_append_engine(az_replay *r, az_engine *e, void *stream);
 /* Append games given as host arrays in the layout of az_example_view (used by tests and by the multi-rank gather). */
 int az_replay_append_host(az_replay *r, const az_example_view *v, int32_t start_ply, void *stream);
 
+/* Append n_games games from a DEVICE buffer in the packed layout of az_engine_export_device (this rank's own export,
+ * or one rank's section of the all-gathered buffer): engine -> RCCL all-gather -> replay store without touching the
+ * host.  The board geometry (max_plies, max_children) is the store's.  Synchronises `stream`. */
+int az_replay_append_device(az_replay *r, const void *dev_buf, int64_t n_games, int32_t start_ply, void *stream);
+
 /* Trainer.remove_duplicates over the whole (flattened) buffer.  Synchronises `stream`.  Records are grouped by the
  * 64-bit history hash; every member of a group is then checked against the group's first record (a second, independent
  * 64-bit hash of the history, the ply and the position): a mismatch - two different histories under one key, which the

@@ -175,37 +175,72 @@ def test_batched_games_with_refill_match_oracle(game, S, n_games, n_slots, nodes
     assert prog["sum_children"] == sum(w["counters"]["sum_children"] for w in want)
 
 
-def test_philox_mode_statistics():
-    """Production RNG (on-device Philox): Dirichlet(0.3) draws and visit-proportional move sampling are
-    checked statistically (north_star: 'within stochastic-sampling tolerance')."""
-    E = _engine_mod()
-    G = 512
-    eng = E.SelfPlayEngine("connect_four", G, n_playouts=8, max_games=G, seed=99)
+def _root_etas(E, game_name, G, seed):
+    """The Dirichlet vector every slot drew for its first root expansion, recovered from the root priors under a uniform
+    evaluator: P = (1 - 0.25) * (1/A) + 0.25 * eta (mcts.py:186-189)."""
+    eng = E.SelfPlayEngine(game_name, G, n_playouts=8, max_games=G, seed=seed)
     eng.reset(G)
     obs, pri, val = eng.alloc_io()   # uniform priors, zero values
     eng.advance(pri, val, obs)       # root requests
-    eng.advance(pri, val, obs)       # consume root eval -> P = 0.75/7 + 0.25*eta
-    etas = []
-    for g in range(G):
-        r = eng.read_root(g)
-        eta = (np.array(r["cP"]) - 0.75 * float(np.float32(1.0 / 7))) / 0.25
-        etas.append(eta)
-    etas = np.array(etas)
+    eng.advance(pri, val, obs)       # consume root eval
+    etas = np.array([(np.array(eng.read_root(g)["cP"]) - 0.75 * float(np.float32(1.0 / eng.A))) / 0.25 for g in range(G)])
+    return eng, (obs, pri, val), etas
+
+
+@pytest.mark.parametrize("game_name,n_legal", [("connect_four", 7), ("breakthrough(rows=6,columns=6)", 16)])
+def test_philox_dirichlet_noise_has_the_right_law(game_name, n_legal):
+    """Production RNG (on-device Philox, fp32 fast-math gamma sampler): eta ~ Dirichlet(0.3 * ones(n_legal)) as
+    np.random.dirichlet draws it at mcts.py:187.  Every component of such a vector is Beta(0.3, 0.3 * (n - 1)):
+    Kolmogorov-Smirnov test of the first, a middle and the last component over 2048 independent games, plus the moments."""
+    from scipy import stats
+    E = _engine_mod()
+    G = 2048
+    eng, _, etas = _root_etas(E, game_name, G, seed=99)
+    eng.close()
+    assert etas.shape == (G, n_legal)
     assert np.allclose(etas.sum(1), 1.0, atol=1e-6) and (etas > -1e-9).all()
-    # Dirichlet(a,...,a) with a=0.3, n=7: mean 1/7, var = (1/7)(6/7)/(7a+1)
-    assert abs(etas.mean() - 1 / 7) < 1e-9 * 7 + 1e-6
-    var = etas.var(0).mean()
-    assert abs(var - (1 / 7) * (6 / 7) / (7 * 0.3 + 1)) < 0.01
-    # distinct games draw distinct noise
-    assert len({tuple(np.round(e, 12)) for e in etas}) == G
-    # finish the first move everywhere and compare the sampled first moves with the visit distribution
-    for _ in range(64):
+    assert len({tuple(np.round(e, 12)) for e in etas}) == G   # distinct games draw distinct noise
+    a, n = 0.3, n_legal
+    for comp in (0, n // 2, n - 1):
+        d, pval = stats.kstest(np.clip(etas[:, comp], 0.0, 1.0), "beta", args=(a, a * (n - 1)))
+        assert pval > 1e-3, (comp, d, pval)
+    assert abs(etas.mean() - 1.0 / n) < 1e-6
+    assert abs(etas.var(0).mean() - (1 / n) * (1 - 1 / n) / (n * a + 1)) < 0.01
+    # components of one vector are negatively correlated: cov(e_i, e_j) = -(1/n^2) / (n a + 1)
+    cov = np.cov(etas[:, 0], etas[:, 1])[0, 1]
+    assert abs(cov + (1 / n ** 2) / (n * a + 1)) < 0.004
+
+
+def test_philox_move_sampling_follows_the_visit_distribution():
+    """alphazerobot.py:75-91 at temperature 1: the move is drawn from the root visit fractions (np.random.choice).
+    Over 4096 first moves, the count of each column against the sum of that column's recorded visit fractions:
+    chi-square, 6 degrees of freedom (the per-game probabilities differ - Poisson-binomial - which only makes the
+    statistic smaller than the multinomial one)."""
+    from scipy import stats
+    E = _engine_mod()
+    G, S = 4096, 24
+    eng = E.SelfPlayEngine("connect_four", G, n_playouts=S, max_games=G, seed=5)
+    eng.reset(G)
+    obs, pri, val = eng.alloc_io()
+    for _ in range(4 * S):
         eng.advance(pri, val, obs)
         if eng.progress()["moves"] >= G:
             break
-    for g in range(G):
-        assert eng.read_slot(g)["ply"] >= 1
+    assert eng.progress()["moves"] >= G
+    # first-ply records of every game (games are still running: read the record store through the device export)
+    ex = E.unpack_device_export(eng.export_device().cpu().numpy(), G, eng.max_plies, eng.max_children)
     eng.close()
+    visits = ex["child_visits"][:, 0, :7].astype(np.float64)
+    assert (ex["n_children"][:, 0] == 7).all() and (visits.sum(1) == S).all()
+    probs = visits / visits.sum(1, keepdims=True)
+    moves = ex["move"][:, 0].astype(np.int64)
+    assert (visits[np.arange(G), moves] > 0).all()          # never an unvisited child
+    observed = np.bincount(moves, minlength=7).astype(np.float64)
+    expected = probs.sum(0)
+    chi2 = float(((observed - expected) ** 2 / expected).sum())
+    assert stats.chi2.sf(chi2, 6) > 1e-3, (chi2, observed, expected)
+    # and the sampling is not simply the argmax: a fair share of games moved to a non-most-visited column
+    assert 0.2 < float((moves != probs.argmax(1)).mean()) < 0.9
 
 
 def test_error_paths():

@@ -41,6 +41,9 @@ def _nets():
         "bt6_ckpt": (bt6, load_npz_checkpoint(os.path.join(GOLDEN, "checkpoint_breakthrough6.npz"), [3, 6, 6], 432)),
         "c4_10block": (c4, Net([3, 6, 7], 7, n_blocks=10, n_filters=50).eval()),
         "bt8_2block": (bt8, Net([3, 8, 8], 768, n_blocks=2, n_filters=50).eval()),
+        # the nets of BASELINE configs 3 and 5 at their full batch sizes (split logits / softmax head kernels)
+        "bt6_10block": (bt6, Net([3, 6, 6], 432, n_blocks=10, n_filters=50).eval()),
+        "bt8_20block": (bt8, Net([3, 8, 8], 768, n_blocks=20, n_filters=50).eval()),
         "bt5x4_3block": (games.load_game("breakthrough(rows=5,columns=4)"),
                          Net([3, 5, 4], 240, n_blocks=3, n_filters=32).eval()),
         # > 50 filters: output-channel tile 3 is streamed in full (the <= 50 case streams 2 of its 16 rows)
@@ -79,7 +82,8 @@ def test_net_matches_reference_golden_outputs():
 @pytest.mark.parametrize("tag,n", [("c4_ckpt", 24), ("c4_ckpt", 1), ("c4_ckpt", 157), ("bt6_ckpt", 40),
                                    ("c4_10block", 300), ("bt8_2block", 37), ("bt5x4_3block", 50),
                                    ("bt4x5_2block", 3), ("bt4x5_2block", 130), ("c4_10block", 4096),
-                                   ("c4_56f_2block", 33), ("c4_56f_2block", 2100)])
+                                   ("c4_56f_2block", 33), ("c4_56f_2block", 2100),
+                                   ("bt6_10block", 4096), ("bt8_20block", 2048)])
 def test_fused_forward_matches_torch(tag, n):
     game, net = _nets()[tag]
     boards = _random_boards(game, n, 7)

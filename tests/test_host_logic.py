@@ -215,6 +215,26 @@ for k in range(w):
         n = int(want["game_len"].max())
         assert (got[k][key].reshape(len(want["game_len"]), -1)[:, :1] == want[key].reshape(len(want["game_len"]), -1)[:, :1]).all()
     assert [len(g) for g in examples_from_export(game, got[k])] == want["game_len"].tolist()
+# the packed DEVICE-export layout (engine.export_device / az_engine_export_device) through the same collective:
+# equal-sized buffers, one all_gather_into_tensor, sections unpack to what each rank packed
+from alphazero_openspiel_amd.engine import device_export_layout, unpack_device_export
+def _packed(k):
+    e = _fake_export(game, n_games=3, seed=200 + k)
+    layout, total = device_export_layout(3, e["move"].shape[1], e["child_action"].shape[2])
+    buf = np.zeros(total, dtype=np.uint8)
+    for name, dt, shape, off in layout:
+        a = np.ascontiguousarray(e[name], dtype=dt).reshape(-1).view(np.uint8)
+        buf[off:off + a.size] = a
+    return e, buf
+mine, buf = _packed(r)
+allb = azdist.all_gather_device_exports(torch.from_numpy(buf)).numpy()
+assert allb.size == w * buf.size
+for k in range(w):
+    want, _ = _packed(k)
+    gotk = unpack_device_export(allb[k * buf.size:(k + 1) * buf.size], 3, want["move"].shape[1], want["child_action"].shape[2])
+    for key in ("game_len", "game_ret0", "states", "move", "n_children", "child_action", "child_visits", "value"):
+        assert (gotk[key] == want[key]).all(), key
+    assert [len(g) for g in examples_from_export(game, gotk)] == want["game_len"].tolist()
 torch.manual_seed(r)
 net = Net([3, 6, 7], 7, n_blocks=2, n_filters=8)
 azdist.broadcast_net(net, src=0)

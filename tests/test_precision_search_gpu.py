@@ -114,8 +114,11 @@ def test_fused_search_stays_within_tolerance_of_fp32_reference_search(which):
         json.dump(out, f, indent=1)
     print(json.dumps(out))
     f16 = out["f16"]
-    # fp16-operand tower: per-search visit vectors within a few percent of the fp32 search's, same preferred move
-    assert f16["visit_l1_over_S_mean"] < 0.03 and f16["argmax_agreement"] > 0.95
+    # fp16-operand tower: per-search visit vectors within a percent or two of the fp32 search's, same preferred move.
+    # Measured (round 2, 1024 games each): random-init 10-block net  mean L1/S 0.0007, argmax agreement 0.999, 98 % of the
+    # games identical move for move; shipped 5-block checkpoint (sharp priors, deeper trees) 0.0085, 0.995, 80 %.
+    l1_tol, agree_tol = {"random10": (0.003, 0.997), "checkpoint5": (0.02, 0.99)}[which]
+    assert f16["visit_l1_over_S_mean"] < l1_tol and f16["argmax_agreement"] > agree_tol
     # outcome and length distributions of 1024 games indistinguishable (means within 3.5 standard errors)
     assert f16["len_diff_in_se"] < 3.5 and f16["ret0_diff_in_se"] < 3.5
     if "f32x" in out:  # split-fp16 ("fp32-grade") tower: tighter than the fp16 one on the like-for-like plies

@@ -159,12 +159,22 @@ def test_engine_to_replay_device_path_matches_host_path(name, backup):
     ev = E.DeviceEvaluator(net, "cuda:0")
     rep = replay.DeviceReplay(name, max_games=40, device=0)
     rep.set_capacity(40)
+    rep_d = replay.DeviceReplay(name, max_games=40, device=0)   # fed through the packed device export instead
+    rep_d.set_capacity(40)
     buffer = []
     for gen in range(2):
         eng = E.SelfPlayEngine(name, 16, n_playouts=8, max_games=24, backup=backup, seed=10 + gen)
         E.run_selfplay(eng, ev, 24)
         rep.append_engine(eng)
-        host_games = E.examples_from_export(game, eng.export())
+        buf = eng.export_device()
+        rep_d.append_device(buf, 24)
+        ex_host = eng.export()
+        ex_dev = E.unpack_device_export(buf.cpu().numpy(), 24, eng.max_plies, eng.max_children)
+        live = np.arange(ex_host["move"].shape[1])[None, :] < ex_host["game_len"][:, None]
+        assert (ex_dev["game_len"] == ex_host["game_len"]).all() and (ex_dev["game_ret0"] == ex_host["game_ret0"]).all()
+        for k in ("move", "n_children", "value", "states"):
+            assert (ex_dev[k][live] == ex_host[k][live]).all(), k
+        host_games = E.examples_from_export(game, ex_host)
         eng.close()
         buffer = pyreplay.fifo_append(buffer, host_games, 40)
         want = pyreplay.remove_duplicates([s for g in buffer for s in g])
@@ -174,8 +184,12 @@ def test_engine_to_replay_device_path_matches_host_path(name, backup):
         assert u["z"].tolist() == [w[3] for w in want]
         boards = games.boards_from_bitboards(game, u["bitboards"], u["ply"])
         assert all((boards[k] == want[k][1]).all() for k in range(len(want)))
+        assert rep_d.dedupe() == len(want)
+        ud = rep_d.read_unique()
+        assert (ud["pi"] == u["pi"]).all() and (ud["z"] == u["z"]).all() and (ud["bitboards"] == u["bitboards"]).all()
     assert rep.stats()["n_games"] == 40 and rep.stats()["games_dropped"] == 8
     rep.close()
+    rep_d.close()
 
 
 @pytest.mark.gpu
