@@ -55,9 +55,12 @@ class AzSlotInfo(C.Structure):
 class AzNetDesc(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("in_planes", C.c_int32),
                 ("n_filters", C.c_int32), ("n_blocks", C.c_int32), ("num_actions", C.c_int32), ("device", C.c_int32),
+                ("precision", C.c_int32), ("reserved", C.c_int32),
                 ("conv_w", C.POINTER(C.c_uint16)), ("conv_epi", C.POINTER(C.c_float)),
                 ("in_affine", C.POINTER(C.c_float)), ("skip_w", C.POINTER(C.c_float)),
-                ("fc_w", C.POINTER(C.c_uint16)), ("fc_b", C.POINTER(C.c_float))]
+                ("fc_w", C.POINTER(C.c_uint16)), ("fc_b", C.POINTER(C.c_float)),
+                ("conv_w_lo", C.POINTER(C.c_uint16)), ("fc_w_lo", C.POINTER(C.c_uint16))]
+NET_PREC = {"f16": 0, "f32x": 1}
 
 
 class AzReplayConfig(C.Structure):

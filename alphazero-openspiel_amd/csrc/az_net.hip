@@ -54,6 +54,7 @@ struct TowerParams {
     float in_scale[8], in_shift[8];
     const float *obs;
     _Float16 *xout;
+    _Float16 *xout_lo; // f16x3: lo halves of the tower output
 };
 
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.01f * v); }
@@ -476,19 +477,360 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
 
 
 // ------------------------------------------------------------------------------------------------
+// az_tower_x3_kernel - the same tower at fp32-GRADE precision on the fp16 matrix pipe ("f16x3", precision AZ_NET_PREC_F16X3).
+//
+// The reference's Net.forward is fp32 (network.py:48-64).  gfx950's f32-input MFMA runs at 1/16 of the f16 rate, so instead
+// every operand is carried as TWO fp16 numbers, x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) * 2048) (the scale
+// keeps lo out of the fp16 subnormals), and a product is three MFMAs with fp32 accumulation:
+//     acc  += W_hi * A_hi                      (exact products, 22-bit)
+//     acc2 += W_hi * A_lo + W_lo * A_hi        (scaled by 2048; the dropped W_lo * A_lo term is ~2^-22 relative)
+//     result = acc + acc2 / 2048
+// i.e. ~22 mantissa bits per product against fp32's 24, at 3/16 of the cost of the f32 MFMA path.  Measured against an fp64
+// evaluation of the same net the error is of the order of torch-fp32's own (tests/test_fused_net.py).
+//
+// Structure: one workgroup = 4 waves (one per SIMD: 36-48 MFMAs per k-step hide the LDS latency without a second wave),
+// one board per wave; the activation image has a hi and a lo set of channel-octet planes; the weight stream carries, per
+// k-step, a hi record followed by a lo record (both in the f16 kernel's record format); epilogues run in fp32 and split
+// their result again.  Tables, tile shapes, the 15-k-step grouping and the LDS-DMA double buffer are those of
+// az_tower_kernel above.
+#define X3_LOFF_RP1 (N_OCT * 96 * OCT_B) // row-pair boards (W <= 7, H <= 6): lo planes sit a compile-time distance after hi
+template <int NT, int CK, bool RP1, int R3>
+__global__ __launch_bounds__(256, 1) void az_tower_x3_kernel(TowerParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int WAVES = 4;
+    constexpr int REC = WRec<R3>::BYTES, REC2 = 2 * REC; // one k-step: hi record, lo record
+    constexpr int CHUNK_B = CK * REC2;
+    constexpr int CHUNK_S = (CHUNK_B + 1023) & ~1023;
+    constexpr bool L15 = R3 < 16;
+    constexpr int NKS = L15 ? 15 : AZ_NET_KSTEPS;
+    constexpr float INV_SPLIT = 1.0f / 2048.0f, SPLIT = 2048.0f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l15 = lane & 15;
+    const int plane_b = p.rcells * OCT_B, region_b = N_OCT * plane_b;
+    const int lo_off = RP1 ? X3_LOFF_RP1 : region_b;
+    const int board0 = blockIdx.x * WAVES + wave;
+    const int region = p.off_act + wave * 2 * lo_off;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const int trash = p.off_epi + 2048 + tid * 16; // per-thread dump slot (hi at +0, lo at +8) for masked-out stores
+
+    { // zero both plane sets (halo + padding must read as 0)
+        uint4 z = {0, 0, 0, 0};
+        for (int i = lane * 16; i < 2 * lo_off; i += 64 * 16) *(uint4 *)(lds + region + i) = z;
+    }
+    int pos_addr[NT], grow[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        int y, x;
+        bool ok;
+        if (p.tpb) {
+            y = 2 * nt + (l15 >> 3);
+            x = l15 & 7;
+            ok = x < p.W && y < p.H && nt < p.tpb;
+        } else {
+            int pos = nt * 16 + l15;
+            y = pos / p.W;
+            x = pos - y * p.W;
+            ok = pos < p.HW;
+        }
+        ok = ok && board0 < p.n_boards;
+        int cell = (y + 1) * p.rs + (x + 1);
+        pos_addr[nt] = region + ((ok || p.tpb) ? cell : p.zcell) * OCT_B;
+        grow[nt] = ok ? board0 * p.HW + y * p.W + x : -1;
+    }
+    int koff[AZ_NET_KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < AZ_NET_KSTEPS; ks++) {
+        int g = 4 * ks + q, tap, c8;
+        bool zero;
+        if (L15) {
+            tap = g / 6, c8 = g - tap * 6;
+            zero = g >= 54;
+        } else {
+            tap = g / 7, c8 = g - tap * 7;
+            zero = g == 63;
+        }
+        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        koff[ks] = zero ? 0 : (dy * p.rs + dx) * OCT_B + c8 * plane_b;
+        if (RP1) koff[ks] += (int)lds_base + pos_addr[0];
+    }
+    int ksp[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int tap = 4 * q + i;
+        tap = tap > 8 ? 8 : tap;
+        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        ksp[i] = (dy * p.rs + dx) * OCT_B + 6 * plane_b;
+        if (RP1) ksp[i] += (int)lds_base + pos_addr[0];
+    }
+    int koff0[AZ_NET_K0STEPS];
+#pragma unroll
+    for (int ks = 0; ks < AZ_NET_K0STEPS; ks++) {
+        int g = 4 * ks + q;
+        int dy = g / 3 - 1, dx = g - (g / 3) * 3 - 1;
+        koff0[ks] = g < 9 ? (dy * p.rs + dx) * OCT_B : 0;
+        if (RP1) koff0[ks] += (int)lds_base + pos_addr[0];
+    }
+
+    // x -> (hi, lo): hi = fp16(x), lo = fp16((x - hi) * 2048)
+    auto split4 = [&](const f32x4 &v, half4 &hi, half4 &lo) {
+        hi = __builtin_convertvector(v, half4);
+        lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * SPLIT, half4);
+    };
+
+    f32x4 acc[4][NT], acc2[4][NT], xres[4][NT];
+    { // prologue: a = lrelu(bn1(x0)) -> octet 0 (hi, lo); block-1 skip conv3(x0) in fp32 -> residual stream
+        f32x4 sw[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sw[mt][r] = *(const f32x4 *)(p.skip_w + (16 * mt + 4 * q + r) * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (grow[nt] >= 0) {
+                int gb = grow[nt] / p.HW, pos = grow[nt] - gb * p.HW;
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (c < p.cin) v[c] = p.obs[((size_t)gb * p.cin + c) * p.HW + pos];
+                if (q == 0) {
+                    f32x4 a;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) a[c] = c < p.cin ? lrelu(p.in_scale[c] * v[c] + p.in_shift[c]) : 0.f;
+                    half4 hi, lo;
+                    split4(a, hi, lo);
+                    *(half4 *)(lds + pos_addr[nt]) = hi;
+                    *(half4 *)(lds + pos_addr[nt] + lo_off) = lo;
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                f32x4 x;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    x[r] = sw[mt][r][0] * v[0] + sw[mt][r][1] * v[1] + sw[mt][r][2] * v[2] + sw[mt][r][3] * v[3];
+                xres[mt][nt] = x;
+                acc[mt][nt] = *(const f32x4 *)(p.epi + 16 * mt + 4 * q);
+                acc2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+
+    constexpr int PARTS = (NKS + CK - 1) / CK;
+    constexpr int C0_B = AZ_NET_K0STEPS * REC2;
+    static_assert(CK % 2 == 0 && AZ_NET_K0STEPS % 2 == 0, "fragment buffer parity relies on an even chunk length");
+    static_assert((PARTS & (PARTS - 1)) == 0 && NKS - (PARTS - 1) * CK >= 3, "chunk index arithmetic / the last two k-steps share a chunk");
+    static_assert((CK - 1) * REC2 + REC + 4 * 1024 <= 65536, "A-fragment offsets must fit the ds offset field");
+    static_assert(C0_B <= CHUNK_B && REC % 16 == 0, "conv 0 must fit a chunk buffer");
+    const int n_chunks = 1 + (p.n_convs - 1) * PARTS;
+    auto issue_bytes = [&](const unsigned char *src, unsigned char *dst, auto bytes_c) {
+        constexpr int NPIECES = (decltype(bytes_c)::value + 1023) / 1024;
+#pragma unroll
+        for (int i = 0; i < (NPIECES + WAVES - 1) / WAVES; i++) {
+            int piece = i * WAVES + wave;
+            if (piece < NPIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_chunk = [&](int c) {
+        const int ci = (c - 1) / PARTS, part = (c - 1) & (PARTS - 1);
+        issue_bytes((const unsigned char *)p.conv_w + C0_B + ((size_t)ci * NKS + (size_t)part * CK) * REC2, lds + (c & 1) * CHUNK_S,
+                    std::integral_constant<int, CHUNK_B>{});
+    };
+    issue_bytes((const unsigned char *)p.conv_w, lds, std::integral_constant<int, C0_B>{});
+    if (wave == 0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(lds + p.off_epi), 16, 0, 0);
+
+    int chunk = 0;
+    auto conv_step = [&](int conv, const auto &kf, auto is_first_c) {
+        constexpr bool IS_FIRST = decltype(is_first_c)::value;
+        constexpr int NPARTS = IS_FIRST ? 1 : PARTS;
+        constexpr int NKSC = IS_FIRST ? AZ_NET_K0STEPS : NKS;
+        constexpr bool HAS_SPECIAL = L15 && !IS_FIRST;
+        half8 ah[2][4], al[2][4], bh[2][NT], bl[2][NT]; // hi / lo fragments, double buffered over k-steps
+        unsigned sph[NT][4], spl[NT][4];                // gather k-step: B fragments dword by dword
+        f32x4 ep_sc[4], ep_sh[4], ep_nb[4];
+        const unsigned ep_base = lds_base + p.off_epi + (conv & 1) * 1024 + q * 16;
+        static_for<NPARTS>([&](auto part_c) {
+            constexpr int part = decltype(part_c)::value;
+            constexpr int CKL = part == NPARTS - 1 ? NKSC - part * CK : CK;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned wbl = lds_base + (chunk & 1) * CHUNK_S + lane * 16;
+            const unsigned wbl3 = R3 == 16 ? wbl
+                                           : lds_base + (chunk & 1) * CHUNK_S +
+                                                 (q * WRec<R3>::ROWS + (l15 < WRec<R3>::ROWS - 1 ? l15 : WRec<R3>::ROWS - 1)) * 16;
+            // read r of k-step ks (compile-time) into fragment buffer `buf`.  Read order inside a k-step:
+            //   A_hi 0..3, A_lo 0..3, then B: plain k-step B_hi 0..NT-1, B_lo 0..NT-1; gather k-step 4 dwords per tile, hi then lo
+            auto read_a = [&](auto buf_c, auto ksl_c, auto r_c) {
+                constexpr int buf = decltype(buf_c)::value, ksl = decltype(ksl_c)::value, r = decltype(r_c)::value;
+                constexpr int mt = r & 3;
+                if constexpr (r < 4) READ_A(ah[buf][mt], mt < 3 ? wbl : wbl3, ksl * REC2 + mt * 1024);
+                else READ_A(al[buf][mt], mt < 3 ? wbl : wbl3, ksl * REC2 + REC + mt * 1024);
+            };
+            auto read_b = [&](auto buf_c, auto ks_c, auto r_c) { // r in [0, 2 NT)
+                constexpr int buf = decltype(buf_c)::value, ks = decltype(ks_c)::value, r = decltype(r_c)::value;
+                constexpr int nt = r % NT;
+                constexpr bool lo = r >= NT;
+                if constexpr (RP1) {
+                    if constexpr (lo) READ_B_OFF(bl[buf][nt], (unsigned)kf[ks], nt * 256 + X3_LOFF_RP1);
+                    else READ_B_OFF(bh[buf][nt], (unsigned)kf[ks], nt * 256);
+                } else {
+                    if constexpr (lo) READ_B(bl[buf][nt], lds_base + pos_addr[nt] + lo_off + opaque(kf[ks]));
+                    else READ_B(bh[buf][nt], lds_base + pos_addr[nt] + opaque(kf[ks]));
+                }
+            };
+            auto read_sp = [&](auto r_c) { // r in [0, 8 NT): tile-major, hi then lo, 4 dwords each
+                constexpr int r = decltype(r_c)::value;
+                constexpr bool lo = r >= 4 * NT;
+                constexpr int nt = (r % (4 * NT)) / 4, i = r % 4;
+                if constexpr (RP1) {
+                    if constexpr (lo) READ_B32_OFF(spl[nt][i], (unsigned)ksp[i], nt * 256 + X3_LOFF_RP1);
+                    else READ_B32_OFF(sph[nt][i], (unsigned)ksp[i], nt * 256);
+                } else {
+                    if constexpr (lo) READ_B32_OFF(spl[nt][i], lds_base + pos_addr[nt] + lo_off + opaque(ksp[i]), 0);
+                    else READ_B32_OFF(sph[nt][i], lds_base + pos_addr[nt] + opaque(ksp[i]), 0);
+                }
+            };
+            static_for<8>([&](auto r_c) { read_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, r_c); });
+            if constexpr (part == 0) // later chunks of a conv had their B fragments fetched before the barrier
+                static_for<2 * NT>([&](auto r_c) { read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, r_c); });
+            // the other weight buffer is free now: fetch the next chunk (issued after the fragment reads so that their
+            // latency hides behind the DMA issue)
+            if (chunk + 1 < n_chunks) issue_chunk(chunk + 1);
+            if (!IS_FIRST && part == 0 && wave == 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + (size_t)conv * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(lds + p.off_epi + (conv & 1) * 1024), 16, 0, 0);
+            static_for<CKL>([&](auto ksl_c) {
+                constexpr int ksl = decltype(ksl_c)::value, ksg = part * CK + ksl;
+                constexpr int cur = ksl & 1, nxt = cur ^ 1;
+                constexpr bool more_here = ksl + 1 < CKL;
+                constexpr bool more_next = !more_here && part + 1 < NPARTS;
+                constexpr bool cur_gather = HAS_SPECIAL && ksg == NKSC - 1;
+                constexpr bool next_gather = HAS_SPECIAL && ksg + 1 == NKSC - 1;
+                constexpr int n_b_next = next_gather ? 8 * NT : 2 * NT;
+                constexpr int n_next = more_here ? 8 + n_b_next : (more_next ? n_b_next : 0);
+                constexpr int ks_next = (more_here || more_next) ? ksg + 1 : 0;
+                constexpr bool last_of_conv = !more_here && !more_next;
+                constexpr int NM = 3 * 4 * NT; // MFMAs of this k-step
+                static_assert(n_next <= NM, "one read of the next k-step per MFMA slot");
+                // every fragment of this k-step was issued at least (NM - n_next) MFMAs ago (or just after the chunk barrier)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (last_of_conv)
+                    static_for<4>([&](auto mt_c) {
+                        constexpr int mt = decltype(mt_c)::value;
+                        if constexpr (!IS_FIRST) {
+                            lds_read_f4_off<256 + mt * 64>(ep_sc[mt], ep_base);
+                            lds_read_f4_off<512 + mt * 64>(ep_sh[mt], ep_base);
+                        }
+                        lds_read_f4_off<768 + mt * 64>(ep_nb[mt], ep_base);
+                    });
+                static_for<NM>([&](auto j_c) {
+                    constexpr int j = decltype(j_c)::value;
+                    constexpr int pass = j / (4 * NT), nt = (j % (4 * NT)) >> 2, mt = j & 3;
+                    if constexpr (j < n_next) { // read j of the next k-step, in its read order
+                        constexpr int r = more_here ? j : j + 8; // a B-only prefetch skips the A slots
+                        if constexpr (r < 8) read_a(std::integral_constant<int, nxt>{}, std::integral_constant<int, ksl + 1>{}, std::integral_constant<int, r>{});
+                        else if constexpr (next_gather) read_sp(std::integral_constant<int, r - 8>{});
+                        else read_b(std::integral_constant<int, nxt>{}, std::integral_constant<int, ks_next>{}, std::integral_constant<int, r - 8>{});
+                    }
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    half8 bhi, blo;
+                    if constexpr (cur_gather) {
+                        const u32x4 uh = {sph[nt][0], sph[nt][1], sph[nt][2], sph[nt][3]};
+                        const u32x4 ul = {spl[nt][0], spl[nt][1], spl[nt][2], spl[nt][3]};
+                        bhi = __builtin_bit_cast(half8, uh);
+                        blo = __builtin_bit_cast(half8, ul);
+                    } else {
+                        bhi = bh[cur][nt];
+                        blo = bl[cur][nt];
+                    }
+                    if constexpr (pass == 0) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][mt], bhi, acc[mt][nt], 0, 0, 0);
+                    else if constexpr (pass == 1) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][mt], blo, acc2[mt][nt], 0, 0, 0);
+                    else acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][mt], bhi, acc2[mt][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            chunk++;
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<4>([&](auto mt_c) {
+            constexpr int mt = decltype(mt_c)::value;
+            if constexpr (!IS_FIRST) {
+                keep_alive(ep_sc[mt]);
+                keep_alive(ep_sh[mt]);
+            }
+            keep_alive(ep_nb[mt]);
+        });
+        // ---- epilogue, in fp32; the result is split into (hi, lo) again ------------------------------------------
+        auto epilogue = [&](auto kind) {
+            constexpr int KIND = decltype(kind)::value; // 0: conv1, 1: conv2 (not last), 2: last conv
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                const int co0 = 16 * mt + 4 * q;
+                const bool wr = (2 * mt + (q >> 1)) < N_OCT;
+                const int woff = (2 * mt + (q >> 1)) * plane_b + (q & 1) * 8;
+                const f32x4 sc = ep_sc[mt], sh = ep_sh[mt], next_bias = ep_nb[mt];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    f32x4 v = acc[mt][nt] + acc2[mt][nt] * INV_SPLIT;
+                    acc[mt][nt] = next_bias;
+                    acc2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    f32x4 o;
+                    if (KIND == 0) {
+                        o = __builtin_elementwise_max(v, v * 0.01f);
+                    } else {
+                        f32x4 xv = xres[mt][nt] + v;
+                        xres[mt][nt] = xv;
+                        if (KIND == 2) {
+                            half4 hi, lo;
+                            split4(xv, hi, lo);
+                            if (grow[nt] >= 0) {
+                                *(half4 *)(p.xout + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = hi;
+                                *(half4 *)(p.xout_lo + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = lo;
+                            }
+                            continue;
+                        }
+                        f32x4 a = __builtin_elementwise_fma(sc, xv, sh);
+                        o = __builtin_elementwise_max(a, a * 0.01f);
+                    }
+                    half4 hi, lo;
+                    split4(o, hi, lo);
+                    const bool live = wr && grow[nt] >= 0;
+                    *(half4 *)(lds + (live ? pos_addr[nt] + woff : trash)) = hi;
+                    *(half4 *)(lds + (live ? pos_addr[nt] + woff + lo_off : trash + 8)) = lo;
+                }
+            }
+        };
+        if constexpr (IS_FIRST) epilogue(std::integral_constant<int, 0>{});
+        else {
+            if (!(conv & 1)) epilogue(std::integral_constant<int, 0>{});
+            else if (conv != p.n_convs - 1) epilogue(std::integral_constant<int, 1>{});
+            else epilogue(std::integral_constant<int, 2>{});
+        }
+    };
+    conv_step(0, koff0, std::true_type{});
+    for (int conv = 1; conv < p.n_convs; conv++) conv_step(conv, koff, std::false_type{});
+}
+
+// ------------------------------------------------------------------------------------------------
 // fc1 + softmax + tanh (network.py:61-64).  One workgroup = 16 boards; the K = HW*64 reduction is split
 // over the 4 waves (k-step ks goes to wave ks & 3), partial tiles are summed through LDS.
 struct HeadParams {
     int HW, A, n_ot, ksteps, n_boards;
     const _Float16 *x;    // [B][HW*64]
     const _Float16 *fc_w; // [n_ot][ksteps][64][8]
+    const _Float16 *x_lo, *fc_w_lo; // f16x3: the lo halves (scaled by 2048), same layouts
     const float *fc_b;
     float *priors, *values;
 };
 
 #define OTG 8
 #define HEAD_NW 8 // waves per workgroup: the K reduction is split over them (memory-bound: more loads in flight per CU)
-__global__ __launch_bounds__(HEAD_NW * 64) void az_head_kernel(HeadParams p) {
+// X3: split-fp16 operands (see az_tower_x3_kernel): three MFMAs per product, result = acc + acc2 / 2048.
+template <bool X3> __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kernel(HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float *part = (float *)lds;                               // [HEAD_NW waves][OTG][64 lanes][4]
     float *logits = (float *)(lds + HEAD_NW * OTG * 64 * 16); // [16][n_ot*16]
@@ -498,10 +840,13 @@ __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kernel(HeadParams p) {
     int row = b0 + l15;
     if (row >= p.n_boards) row = p.n_boards - 1; // clamp: computed, never stored
     const _Float16 *xrow = p.x + (size_t)row * K + 8 * q;
+    const _Float16 *xrow_lo = X3 ? p.x_lo + (size_t)row * K + 8 * q : nullptr;
     for (int og = 0; og < p.n_ot; og += OTG) {
-        f32x4 acc[OTG];
+        f32x4 acc[OTG], acc2[X3 ? OTG : 1];
 #pragma unroll
         for (int o = 0; o < OTG; o++) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < (X3 ? OTG : 1); o++) acc2[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (p.n_ot == 1) { // small action space (connect_four): one output tile -> a pure chain of load, load, MFMA per
                            // k-step; unrolled so that the loads of several k-steps are in flight together
 #pragma unroll 8
@@ -509,19 +854,36 @@ __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kernel(HeadParams p) {
                 half8 a = *(const half8 *)(xrow + 32 * ks);
                 half8 w = *(const half8 *)(p.fc_w + ((size_t)ks * 64 + lane) * 8);
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w, acc[0], 0, 0, 0);
+                if constexpr (X3) {
+                    half8 al = *(const half8 *)(xrow_lo + 32 * ks);
+                    half8 wl = *(const half8 *)(p.fc_w_lo + ((size_t)ks * 64 + lane) * 8);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wl, acc2[0], 0, 0, 0);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, w, acc2[0], 0, 0, 0);
+                }
             }
         } else
         for (int ks = wave; ks < p.ksteps; ks += HEAD_NW) {
             half8 a = *(const half8 *)(xrow + 32 * ks);
+            half8 al;
+            if constexpr (X3) al = *(const half8 *)(xrow_lo + 32 * ks);
 #pragma unroll
             for (int o = 0; o < OTG; o++)
                 if (og + o < p.n_ot) {
-                    half8 w = *(const half8 *)(p.fc_w + (((size_t)(og + o) * p.ksteps + ks) * 64 + lane) * 8);
+                    const size_t wi = (((size_t)(og + o) * p.ksteps + ks) * 64 + lane) * 8;
+                    half8 w = *(const half8 *)(p.fc_w + wi);
                     acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w, acc[o], 0, 0, 0);
+                    if constexpr (X3) {
+                        half8 wl = *(const half8 *)(p.fc_w_lo + wi);
+                        acc2[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wl, acc2[o], 0, 0, 0);
+                        acc2[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, w, acc2[o], 0, 0, 0);
+                    }
                 }
         }
 #pragma unroll
-        for (int o = 0; o < OTG; o++) *(f32x4 *)(part + ((wave * OTG + o) * 64 + lane) * 4) = acc[o];
+        for (int o = 0; o < OTG; o++) {
+            if constexpr (X3) acc[o] = acc[o] + acc2[o] * (1.0f / 2048.0f);
+            *(f32x4 *)(part + ((wave * OTG + o) * 64 + lane) * 4) = acc[o];
+        }
         __syncthreads();
         // the threads sum the HEAD_NW partials of OTG*64 float4 slots
         for (int s = tid; s < OTG * 64; s += HEAD_NW * 64) {
@@ -545,13 +907,17 @@ __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kernel(HeadParams p) {
 #pragma unroll
     for (int off = 8; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
     float sum = 0.f;
-    for (int o = sub; o < p.A; o += 16) sum += __expf(lg[o] - mx);
+    for (int o = sub; o < p.A; o += 16) sum += X3 ? expf(lg[o] - mx) : __expf(lg[o] - mx);
 #pragma unroll
     for (int off = 8; off; off >>= 1) sum += __shfl_xor(sum, off, 16);
     if (tid < 256 && b0 + brd < p.n_boards) {
-        float inv = 1.f / sum;
         float *out = p.priors + (size_t)(b0 + brd) * p.A;
-        for (int o = sub; o < p.A; o += 16) out[o] = __expf(lg[o] - mx) * inv;
+        if (X3) {
+            for (int o = sub; o < p.A; o += 16) out[o] = expf(lg[o] - mx) / sum;
+        } else {
+            float inv = 1.f / sum;
+            for (int o = sub; o < p.A; o += 16) out[o] = __expf(lg[o] - mx) * inv;
+        }
         if (sub == 0) p.values[b0 + brd] = tanhf(lg[p.A]);
     }
 }
@@ -559,7 +925,7 @@ __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kernel(HeadParams p) {
 // Large action spaces (breakthrough: 433 / 769 outputs = 28 / 49 output tiles): the single-kernel head above keeps only
 // 4 waves per CU busy on a latency-bound loop (measured 0.15 ms for 4096 boards at A = 432).  Split: a logits kernel
 // over (board tile, group of OTG output tiles) -> 4-7x the workgroups, logits to HBM (fp32), then a softmax kernel.
-__global__ __launch_bounds__(256) void az_head_logits_kernel(HeadParams p, float *__restrict__ logits_g) {
+template <bool X3> __global__ __launch_bounds__(256) void az_head_logits_kernel(HeadParams p, float *__restrict__ logits_g) {
     __shared__ __attribute__((aligned(16))) float part[4 * OTG * 64 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l15 = lane & 15;
     const int b0 = blockIdx.x * 16, og = blockIdx.y * OTG;
@@ -567,21 +933,35 @@ __global__ __launch_bounds__(256) void az_head_logits_kernel(HeadParams p, float
     int row = b0 + l15;
     if (row >= p.n_boards) row = p.n_boards - 1;
     const _Float16 *xrow = p.x + (size_t)row * K + 8 * q;
-    f32x4 acc[OTG];
+    const _Float16 *xrow_lo = X3 ? p.x_lo + (size_t)row * K + 8 * q : nullptr;
+    f32x4 acc[OTG], acc2[X3 ? OTG : 1];
 #pragma unroll
     for (int o = 0; o < OTG; o++) acc[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < (X3 ? OTG : 1); o++) acc2[o] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
     for (int ks = wave; ks < p.ksteps; ks += 4) {
         half8 a = *(const half8 *)(xrow + 32 * ks);
+        half8 al;
+        if constexpr (X3) al = *(const half8 *)(xrow_lo + 32 * ks);
 #pragma unroll
         for (int o = 0; o < OTG; o++)
             if (og + o < p.n_ot) {
-                half8 w = *(const half8 *)(p.fc_w + (((size_t)(og + o) * p.ksteps + ks) * 64 + lane) * 8);
+                const size_t wi = (((size_t)(og + o) * p.ksteps + ks) * 64 + lane) * 8;
+                half8 w = *(const half8 *)(p.fc_w + wi);
                 acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w, acc[o], 0, 0, 0);
+                if constexpr (X3) {
+                    half8 wl = *(const half8 *)(p.fc_w_lo + wi);
+                    acc2[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wl, acc2[o], 0, 0, 0);
+                    acc2[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, w, acc2[o], 0, 0, 0);
+                }
             }
     }
 #pragma unroll
-    for (int o = 0; o < OTG; o++) *(f32x4 *)(part + ((wave * OTG + o) * 64 + lane) * 4) = acc[o];
+    for (int o = 0; o < OTG; o++) {
+        if constexpr (X3) acc[o] = acc[o] + acc2[o] * (1.0f / 2048.0f);
+        *(f32x4 *)(part + ((wave * OTG + o) * 64 + lane) * 4) = acc[o];
+    }
     __syncthreads();
     for (int s = tid; s < OTG * 64; s += 256) {
         int o = s >> 6, ln = s & 63;
@@ -598,7 +978,7 @@ __global__ __launch_bounds__(256) void az_head_logits_kernel(HeadParams p, float
         }
     }
 }
-__global__ __launch_bounds__(256) void az_head_softmax_kernel(HeadParams p, const float *__restrict__ logits_g) {
+template <bool X3> __global__ __launch_bounds__(256) void az_head_softmax_kernel(HeadParams p, const float *__restrict__ logits_g) {
     const int tid = threadIdx.x, brd = tid >> 4, sub = tid & 15;
     const int b = blockIdx.x * 16 + brd, NP = p.n_ot * 16;
     const float *lg = logits_g + (size_t)(b < p.n_boards ? b : p.n_boards - 1) * NP;
@@ -607,13 +987,17 @@ __global__ __launch_bounds__(256) void az_head_softmax_kernel(HeadParams p, cons
 #pragma unroll
     for (int off = 8; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
     float sum = 0.f;
-    for (int o = sub; o < p.A; o += 16) sum += __expf(lg[o] - mx);
+    for (int o = sub; o < p.A; o += 16) sum += X3 ? expf(lg[o] - mx) : __expf(lg[o] - mx);
 #pragma unroll
     for (int off = 8; off; off >>= 1) sum += __shfl_xor(sum, off, 16);
     if (b < p.n_boards) {
-        float inv = 1.f / sum;
         float *out = p.priors + (size_t)b * p.A;
-        for (int o = sub; o < p.A; o += 16) out[o] = __expf(lg[o] - mx) * inv;
+        if (X3) {
+            for (int o = sub; o < p.A; o += 16) out[o] = expf(lg[o] - mx) / sum;
+        } else {
+            float inv = 1.f / sum;
+            for (int o = sub; o < p.A; o += 16) out[o] = __expf(lg[o] - mx) * inv;
+        }
         if (sub == 0) p.values[b] = tanhf(lg[p.A]);
     }
 }
@@ -623,10 +1007,12 @@ struct az_net {
     az_net_desc d;
     std::string err;
     _Float16 *conv_w = nullptr, *fc_w = nullptr, *xout = nullptr;
+    _Float16 *fc_w_lo = nullptr, *xout_lo = nullptr; // f16x3 only
     float *epi = nullptr, *fc_b = nullptr, *skip_w = nullptr, *logits = nullptr;
     float in_affine[16];
     int max_boards = 0;
     int bpw_max = 0, lds_head = 0, n_ot = 0, r3 = 16;
+    int precision = AZ_NET_PREC_F16;
 };
 static std::string g_net_err;
 
@@ -646,6 +1032,8 @@ extern "C" int az_net_destroy(az_net *n) {
     (void)hipSetDevice(n->d.device);
     (void)hipFree(n->conv_w);
     (void)hipFree(n->fc_w);
+    (void)hipFree(n->fc_w_lo);
+    (void)hipFree(n->xout_lo);
     (void)hipFree(n->xout);
     (void)hipFree(n->epi);
     (void)hipFree(n->fc_b);
@@ -689,6 +1077,38 @@ static TowerGeom tower_geom(int bpw, int waves, int H, int W) {
     return g;
 }
 
+// geometry of the f16x3 tower: one board per wave, 4 waves, 4-k-step chunks of (hi, lo) records
+struct X3Geom {
+    int nt, rcells, zcell, rs, tpb, cells, off_epi, off_act, lds, lo_off;
+    bool rp1;
+};
+static X3Geom x3_geom(int H, int W, int r3) {
+    X3Geom g;
+    if (W <= 7) {
+        g.rs = 8;
+        g.tpb = (H + 1) / 2;
+        g.nt = g.tpb;
+    } else {
+        g.rs = W + 1;
+        g.tpb = 0;
+        g.nt = (H * W + 15) / 16;
+    }
+    g.cells = (H + 2) * g.rs + 1;
+    int zpad = 2 * (g.rs + 1) + 1;
+    g.rcells = (g.cells + zpad + 15) & ~15;
+    g.zcell = g.cells + (g.rs + 1);
+    g.rp1 = g.tpb && g.rs == 8 && g.tpb <= 3 && g.rcells <= 96;
+    const int region_b = N_OCT * g.rcells * OCT_B;
+    g.lo_off = g.rp1 ? X3_LOFF_RP1 : region_b;
+    const int rows = r3 < 16 ? r3 + 1 : 16, rec = 3 * 1024 + 4 * rows * 16;
+    const int chunk_s = (4 * 2 * rec + 1023) & ~1023;
+    g.off_epi = 2 * chunk_s;
+    g.off_act = g.off_epi + 2048 + 256 * 16;
+    g.lds = g.off_act + 4 * 2 * g.lo_off;
+    if (g.nt < 3) g.nt = 3;
+    return g;
+}
+
 extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     if (!desc || !out) {
         g_net_err = "null argument";
@@ -706,10 +1126,27 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
         g_net_err = "bad net description (need 3<=rows,cols, rows*cols<=64, in_planes<=4, n_filters<=56, packed buffers)";
         return AZ_E_INVALID;
     }
+    if (d.precision != AZ_NET_PREC_F16 && d.precision != AZ_NET_PREC_F16X3) {
+        g_net_err = "precision must be AZ_NET_PREC_F16 or AZ_NET_PREC_F16X3";
+        return AZ_E_INVALID;
+    }
+    if (d.precision == AZ_NET_PREC_F16X3 && (!d.conv_w_lo || !d.fc_w_lo)) {
+        g_net_err = "AZ_NET_PREC_F16X3 needs conv_w_lo and fc_w_lo";
+        return AZ_E_INVALID;
+    }
     az_net *n = new az_net();
     n->d = d;
+    n->precision = d.precision;
     memcpy(n->in_affine, d.in_affine, sizeof n->in_affine);
     const int HW = d.rows * d.cols;
+    if (n->precision == AZ_NET_PREC_F16X3) {
+        X3Geom g = x3_geom(d.rows, d.cols, d.n_filters <= 50 ? 2 : 16);
+        if (g.nt > 4 || g.lds > 160 * 1024) {
+            g_net_err = "board / filter count does not fit the f16x3 tower kernel's LDS budget";
+            delete n;
+            return AZ_E_INVALID;
+        }
+    }
     // boards per wave: at most 4 column tiles per wave (larger tiles spill registers under the hand-scheduled k-loop
     // and measured slower than more, smaller waves) within the 160 KiB LDS
     int best = 0;
@@ -752,8 +1189,9 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
         const int rows = n->r3 < 16 ? n->r3 + 1 : 16, rec = 3 * 1024 + 4 * rows * 16;
         const int n_convs = 2 * d.n_blocks;
         const size_t conv_b = (size_t)AZ_NET_KSTEPS * 4096;
-        std::vector<unsigned char> dev((size_t)(AZ_NET_K0STEPS + (size_t)(n_convs - 1) * nks) * rec + 8 * 4096 + 1024, 0); // + a chunk of padding
-        const unsigned char *src = (const unsigned char *)d.conv_w;
+        const size_t n_rec = (size_t)AZ_NET_K0STEPS + (size_t)(n_convs - 1) * nks;
+        auto build_records = [&](const unsigned char *src, std::vector<unsigned char> &dev) { // one `rec`-byte record per k-step
+        dev.assign(n_rec * rec, 0);
         auto put_record = [&](unsigned char *dst, const unsigned char *ks4k) { // ks4k: [4 mt][64 lanes][16 B]
             memcpy(dst, ks4k, 3 * 1024);
             for (int q = 0; q < 4; q++)
@@ -803,6 +1241,22 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
                     }
                 put_record(&dev[off], (const unsigned char *)k4.data());
             }
+        };
+        std::vector<unsigned char> hi, dev;
+        build_records((const unsigned char *)d.conv_w, hi);
+        const size_t pad = 2 * 8 * 4096 + 1024; // a chunk of padding: the last (short) chunk is fetched at full length
+        if (n->precision == AZ_NET_PREC_F16X3) { // per k-step: hi record, lo record
+            std::vector<unsigned char> lo;
+            build_records((const unsigned char *)d.conv_w_lo, lo);
+            dev.assign(2 * n_rec * rec + pad, 0);
+            for (size_t r = 0; r < n_rec; r++) {
+                memcpy(&dev[2 * r * rec], &hi[r * rec], rec);
+                memcpy(&dev[(2 * r + 1) * rec], &lo[r * rec], rec);
+            }
+        } else {
+            dev = hi;
+            dev.resize(n_rec * rec + pad, 0);
+        }
         up((void **)&n->conv_w, dev.data(), dev.size());
     }
     {   // [conv][3][64] (ABI) -> [conv][4][64] with the NEXT conv's bias in row 3 (what the kernel's ring slot holds)
@@ -815,12 +1269,15 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
         up((void **)&n->epi, e4.data(), e4.size() * sizeof(float));
     }
     up((void **)&n->fc_w, d.fc_w, fw);
+    if (n->precision == AZ_NET_PREC_F16X3) up((void **)&n->fc_w_lo, d.fc_w_lo, fw);
     up((void **)&n->fc_b, d.fc_b, fb);
     up((void **)&n->skip_w, d.skip_w, 64 * 4 * sizeof(float));
     if (rc != AZ_OK) {
         az_net_destroy(n);
         return rc;
     }
+    n->d.conv_w_lo = nullptr;
+    n->d.fc_w_lo = nullptr;
     n->d.conv_w = nullptr; // host pointers are not kept
     n->d.conv_epi = nullptr;
     n->d.in_affine = nullptr;
@@ -839,6 +1296,12 @@ extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
     size_t bytes = (size_t)max_boards * n->d.rows * n->d.cols * AZ_NET_XOUT_C * 2;
     NCHK(n, hipMalloc((void **)&n->xout, bytes));
     NCHK(n, hipMemset(n->xout, 0, bytes));
+    if (n->xout_lo) (void)hipFree(n->xout_lo);
+    n->xout_lo = nullptr;
+    if (n->precision == AZ_NET_PREC_F16X3) {
+        NCHK(n, hipMalloc((void **)&n->xout_lo, bytes));
+        NCHK(n, hipMemset(n->xout_lo, 0, bytes));
+    }
     if (n->logits) (void)hipFree(n->logits);
     n->logits = nullptr;
     if (n->n_ot > OTG) NCHK(n, hipMalloc((void **)&n->logits, (size_t)max_boards * n->n_ot * 16 * sizeof(float)));
@@ -872,6 +1335,38 @@ template <int NT> static hipError_t launch_tower_ck(const az_net *n, const Tower
     return g.ck == 8 ? launch_tower<NT, 8, 4>(n, tp, grid, g.lds, st) : launch_tower<NT, 4, 4>(n, tp, grid, g.lds, st);
 }
 
+template <int NT, bool RP1, int R3> static hipError_t launch_x3_r3(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
+    static bool attr_set[AZ_MAX_DEVICES] = {false};
+    const int dv = n->d.device;
+    if (dv < 0 || dv >= AZ_MAX_DEVICES || !attr_set[dv]) {
+        hipError_t s = hipFuncSetAttribute((const void *)az_tower_x3_kernel<NT, 4, RP1, R3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (s != hipSuccess) return s;
+        if (dv >= 0 && dv < AZ_MAX_DEVICES) attr_set[dv] = true;
+    }
+    hipLaunchKernelGGL((az_tower_x3_kernel<NT, 4, RP1, R3>), dim3(grid), dim3(256), lds, st, tp);
+    return hipGetLastError();
+}
+template <int NT, bool RP1> static hipError_t launch_x3(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
+    return n->r3 == 2 ? launch_x3_r3<NT, RP1, 2>(n, tp, grid, lds, st) : launch_x3_r3<NT, RP1, 16>(n, tp, grid, lds, st);
+}
+
+template <bool X3> static int launch_head(az_net *n, const HeadParams &hp, int n_boards, hipStream_t st) {
+    if (n->n_ot > OTG) { // large action space: logits over (board tile x output-tile group), then softmax
+        hipLaunchKernelGGL(az_head_logits_kernel<X3>, dim3((n_boards + 15) / 16, (n->n_ot + OTG - 1) / OTG), dim3(256), 0, st, hp, n->logits);
+        hipLaunchKernelGGL(az_head_softmax_kernel<X3>, dim3((n_boards + 15) / 16), dim3(256), 0, st, hp, (const float *)n->logits);
+    } else {
+        static bool head_attr[AZ_MAX_DEVICES] = {false};
+        const int dv = n->d.device;
+        if (dv < 0 || dv >= AZ_MAX_DEVICES || !head_attr[dv]) {
+            NCHK(n, hipFuncSetAttribute((const void *)az_head_kernel<X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (dv >= 0 && dv < AZ_MAX_DEVICES) head_attr[dv] = true;
+        }
+        hipLaunchKernelGGL(az_head_kernel<X3>, dim3((n_boards + 15) / 16), dim3(HEAD_NW * 64), n->lds_head, st, hp);
+    }
+    NCHK(n, hipGetLastError());
+    return AZ_OK;
+}
+
 extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float *values, int32_t n_boards, void *stream) {
     if (!n || !obs || !priors || !values || n_boards < 1) return AZ_E_INVALID;
     if (n_boards > n->max_boards) {
@@ -880,6 +1375,54 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     }
     NCHK(n, hipSetDevice(n->d.device)); // the launch must pair `stream` with the device the net lives on
     hipStream_t st = (hipStream_t)stream;
+    HeadParams hp;
+    hp.HW = n->d.rows * n->d.cols;
+    hp.A = n->d.num_actions;
+    hp.n_ot = n->n_ot;
+    hp.ksteps = hp.HW * AZ_NET_XOUT_C / 32;
+    hp.n_boards = n_boards;
+    hp.x = n->xout;
+    hp.x_lo = n->xout_lo;
+    hp.fc_w = n->fc_w;
+    hp.fc_w_lo = n->fc_w_lo;
+    hp.fc_b = n->fc_b;
+    hp.priors = priors;
+    hp.values = values;
+    if (n->precision == AZ_NET_PREC_F16X3) { // split-fp16 tower: one board per wave, 4 waves per workgroup
+        const X3Geom g = x3_geom(n->d.rows, n->d.cols, n->r3);
+        TowerParams tp;
+        tp.H = n->d.rows;
+        tp.W = n->d.cols;
+        tp.HW = tp.H * tp.W;
+        tp.cells = g.cells;
+        tp.rs = g.rs;
+        tp.tpb = g.tpb;
+        tp.off_epi = g.off_epi;
+        tp.off_act = g.off_act;
+        tp.cin = n->d.in_planes;
+        tp.n_convs = 2 * n->d.n_blocks;
+        tp.n_boards = n_boards;
+        tp.bpw = 1;
+        tp.rcells = g.rcells;
+        tp.zcell = g.zcell;
+        tp.conv_w = n->conv_w;
+        tp.epi = n->epi;
+        tp.skip_w = n->skip_w;
+        memcpy(tp.in_scale, n->in_affine, 32);
+        memcpy(tp.in_shift, n->in_affine + 8, 32);
+        tp.obs = obs;
+        tp.xout = n->xout;
+        tp.xout_lo = n->xout_lo;
+        const int grid = (n_boards + 3) / 4;
+        hipError_t s;
+        if (g.nt <= 3) s = g.rp1 ? launch_x3<3, true>(n, tp, grid, g.lds, st) : launch_x3<3, false>(n, tp, grid, g.lds, st);
+        else s = launch_x3<4, false>(n, tp, grid, g.lds, st);
+        if (s != hipSuccess) {
+            n->err = std::string("f16x3 tower launch: ") + hipGetErrorString(s);
+            return AZ_E_HIP;
+        }
+        return launch_head<true>(n, hp, n_boards, st);
+    }
     // boards per wave: one workgroup (4 waves) per CU is resident, a launch runs in ceil(WGs / 256) rounds and a
     // round costs ~ (column tiles + fixed part): pick the bpw that minimises rounds x tiles for THIS batch size.
     // Work partition for THIS batch size.  Candidates: boards per wave x {4, 8} waves per workgroup.  A launch runs in
@@ -924,6 +1467,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     memcpy(tp.in_shift, n->in_affine + 8, 32);
     tp.obs = obs;
     tp.xout = n->xout;
+    tp.xout_lo = nullptr;
     int per_wg = g.waves * g.bpw, grid = (n_boards + per_wg - 1) / per_wg;
     hipError_t s;
     switch (g.nt < 3 ? 3 : g.nt) {
@@ -934,31 +1478,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         n->err = std::string("tower launch: ") + hipGetErrorString(s);
         return AZ_E_HIP;
     }
-    HeadParams hp;
-    hp.HW = tp.HW;
-    hp.A = n->d.num_actions;
-    hp.n_ot = n->n_ot;
-    hp.ksteps = tp.HW * AZ_NET_XOUT_C / 32;
-    hp.n_boards = n_boards;
-    hp.x = n->xout;
-    hp.fc_w = n->fc_w;
-    hp.fc_b = n->fc_b;
-    hp.priors = priors;
-    hp.values = values;
-    if (n->n_ot > OTG) { // large action space: logits over (board tile x output-tile group), then softmax
-        hipLaunchKernelGGL(az_head_logits_kernel, dim3((n_boards + 15) / 16, (n->n_ot + OTG - 1) / OTG), dim3(256), 0, st, hp, n->logits);
-        hipLaunchKernelGGL(az_head_softmax_kernel, dim3((n_boards + 15) / 16), dim3(256), 0, st, hp, (const float *)n->logits);
-    } else {
-        static bool head_attr[AZ_MAX_DEVICES] = {false};
-        const int dv = n->d.device;
-        if (dv < 0 || dv >= AZ_MAX_DEVICES || !head_attr[dv]) {
-            NCHK(n, hipFuncSetAttribute((const void *)az_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            if (dv >= 0 && dv < AZ_MAX_DEVICES) head_attr[dv] = true;
-        }
-        hipLaunchKernelGGL(az_head_kernel, dim3((n_boards + 15) / 16), dim3(HEAD_NW * 64), n->lds_head, st, hp);
-    }
-    NCHK(n, hipGetLastError());
-    return AZ_OK;
+    return launch_head<false>(n, hp, n_boards, st);
 }
 
 extern "C" int az_net_read_tower(az_net *n, float *out, int32_t n_boards) {

@@ -26,6 +26,15 @@
 extern "C" {
 #endif
 
+/* Arithmetic of the matrix products (both accumulate in fp32; the residual stream, biases and BatchNorm affines are fp32):
+ *   AZ_NET_PREC_F16    fp16 operands: one MFMA per product.  |dprior| <= 4e-3, |dvalue| <= 8e-3 against the reference's
+ *                      fp32 Net.forward; search-level tolerance measured in tests/test_precision_search_gpu.py.
+ *   AZ_NET_PREC_F16X3  fp32-grade: every operand is a pair of fp16 numbers (hi + lo / 2048), three MFMAs per product
+ *                      (hi*hi + hi*lo + lo*hi), ~22 mantissa bits per product.  The reference's arithmetic is fp32
+ *                      (network.py:48-64); gfx950's f32-input MFMA runs at 1/16 of the fp16 rate, this runs at 1/3. */
+#define AZ_NET_PREC_F16 0
+#define AZ_NET_PREC_F16X3 1
+
 #define AZ_NET_CPAD 56      /* channels per LDS cell: 7 groups of 8 (n_filters <= 56) */
 #define AZ_NET_KSTEPS 16    /* 32-deep MFMA k-steps per conv: 64 groups x 8 */
 #define AZ_NET_XOUT_C 64    /* channel stride of the tower output handed to the FC kernel */
@@ -38,6 +47,8 @@ typedef struct az_net_desc {
     int32_t n_blocks;       /* 5 in the reference (network.py:39-43) */
     int32_t num_actions;    /* A; fc1 has A+1 outputs (network.py:45) */
     int32_t device;
+    int32_t precision;      /* AZ_NET_PREC_* */
+    int32_t reserved;
     /* host pointers to the packed parameters (copied by az_net_create) */
     const uint16_t *conv_w; /* fp16 bits [2*n_blocks][16 ksteps][4 mtiles][64 lanes][8]: the interchange layout (group g = tap * 7 + channel
                              * octet); az_net_create re-groups it for the device (conv 0: 4 k-steps; <= 50 filters: 15 k-steps) */
@@ -46,6 +57,9 @@ typedef struct az_net_desc {
     const float *skip_w;    /* [64][4]: block-1 conv3 (1x1) weights, out-channel major, zero padded */
     const uint16_t *fc_w;   /* fp16 bits [n_otiles][H*W*64/32 ksteps][64 lanes][8] */
     const float *fc_b;      /* [n_otiles*16] (bias of fc1, zero padded) */
+    /* AZ_NET_PREC_F16X3 only: the "lo" halves, fp16 bits of (w - fp16(w)) * 2048, in the layouts of conv_w / fc_w */
+    const uint16_t *conv_w_lo;
+    const uint16_t *fc_w_lo;
 } az_net_desc;
 
 typedef struct az_net az_net;

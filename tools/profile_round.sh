@@ -1,0 +1,17 @@
+#!/bin/bash
+# rocprofv3 evidence for the default bench command (run on the GPU box; copy the summaries into profiles/).
+# Counters go in their own passes (8 SQ slots; FETCH_SIZE and WRITE_SIZE cannot share a pass); no trace domains beside --pmc.
+set -x
+export TMPDIR=/tmp
+OUT=${1:-gpurun_out/prof}
+B="bench.py --cpu-baseline off --ref-seconds 0 --steps 1 --warmup 0"
+rocprofv3 -L > $OUT.counters.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -- python3 bench.py --cpu-baseline off --ref-seconds 0 > $OUT.trace_bench.json 2> $OUT.trace.err
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/sq1 -- python3 $B > $OUT.sq1.json 2> $OUT.sq1.err
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU -d $OUT/sq2 -- python3 $B > $OUT.sq2.json 2> $OUT.sq2.err
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- python3 $B > $OUT.fetch.json 2> $OUT.fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- python3 $B > $OUT.write.json 2> $OUT.write.err
+python3 tools/pmc_summary.py $OUT/trace $OUT/sq1 $OUT/sq2 $OUT/fetch $OUT/write > $OUT.summary.txt 2>&1
+rm -rf $OUT/sq1 $OUT/sq2 $OUT/fetch $OUT/write   # raw per-dispatch CSVs are large; the summary is what is kept
+find $OUT/trace -name "*.csv" ! -name "*kernel_stats.csv" -delete
+echo profiled
