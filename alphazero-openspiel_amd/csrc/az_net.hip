@@ -1489,5 +1489,9 @@ extern "C" int az_net_read_tower(az_net *n, float *out, int32_t n_boards) {
     std::vector<_Float16> h(cnt);
     NCHK(n, hipMemcpy(h.data(), n->xout, cnt * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < cnt; i++) out[i] = (float)h[i];
+    if (n->precision == AZ_NET_PREC_F16X3) { // hi + lo / 2048
+        NCHK(n, hipMemcpy(h.data(), n->xout_lo, cnt * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; i++) out[i] += (float)h[i] * (1.0f / 2048.0f);
+    }
     return AZ_OK;
 }

@@ -40,6 +40,9 @@ class ExampleGenerator:
         self.n_slots = kwargs.get("n_slots")           # concurrent games per GPU; default min(n_games, 4096)
         self.seed = int(kwargs.get("seed", np.random.randint(0, 2 ** 31 - 1)))
         self.eval_backend = kwargs.get("eval_backend", "fused")   # "fused" (csrc/az_net.hip) | "torch"
+        # fused backend: "f32x" = fp32-grade (split-fp16 operands, the reference's Net.forward is fp32: network.py:48-64);
+        # "f16" = fp16 operands, ~2.5x the throughput, opt-in (tolerances: tests/test_precision_search_gpu.py)
+        self.eval_precision = kwargs.get("eval_precision", "f32x")
         self.eval_dtype = kwargs.get("eval_dtype", torch.float32)   # torch backend only
         self.use_graph = bool(kwargs.get("use_graph", True))
         self.overlap = int(kwargs.get("overlap", 1))  # slot groups ticking on their own HIP streams (engine.run_selfplay)
@@ -69,7 +72,7 @@ class ExampleGenerator:
             sizes = [n for _, n in slot_groups(n_slots, self.overlap)] if self.overlap > 1 else [n_slots]
             if self.eval_backend == "fused":
                 from .fusednet import FusedNet
-                evaluators = [FusedNet(self.net, self.device, max_boards=n) for n in sizes]
+                evaluators = [FusedNet(self.net, self.device, max_boards=n, precision=self.eval_precision) for n in sizes]
             else:
                 evaluators = [DeviceEvaluator(self.net, self.device, dtype=self.eval_dtype) for _ in sizes]
             self.last_progress = run_selfplay(engine, evaluators if self.overlap > 1 else evaluators[0], n_local,

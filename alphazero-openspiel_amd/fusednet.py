@@ -36,8 +36,18 @@ def _bn_affine(bn):
     return s.numpy(), t.numpy()
 
 
+SPLIT_SCALE = 2048.0  # f16x3: x = hi + lo / 2048, hi = fp16(x), lo = fp16((x - hi) * 2048)
+
+
+def split_fp16(a):
+    """float64 array -> (hi, lo) fp16 arrays of the f16x3 representation."""
+    hi = a.astype(np.float16)
+    lo = ((a - hi.astype(np.float64)) * SPLIT_SCALE).astype(np.float16)
+    return hi, lo
+
+
 def _pack_conv(w3x3):
-    """w3x3: float64 [F, Cin, 3, 3] (already folded) -> fp16 bits [16, 4, 64, 8]."""
+    """w3x3: float64 [F, Cin, 3, 3] (already folded) -> (hi, lo) fp16 bits [16, 4, 64, 8] each."""
     F_, cin = w3x3.shape[0], w3x3.shape[1]
     assert F_ <= 64 and cin <= CPAD
     dense = np.zeros((64, NGROUPS, 8), dtype=np.float64)  # [co][group][j]
@@ -48,12 +58,13 @@ def _pack_conv(w3x3):
             ci = 8 * c8 + j
             if ci < cin:
                 dense[:F_, g, j] = w3x3[:, ci, ky, kx]
-    out = np.zeros((KSTEPS, 4, 64, 8), dtype=np.float16)
+    out = np.zeros((KSTEPS, 4, 64, 8), dtype=np.float64)
     lane = np.arange(64)
     for ks in range(KSTEPS):
         for mt in range(4):
-            out[ks, mt] = dense[16 * mt + (lane & 15), 4 * ks + (lane >> 4), :].astype(np.float16)
-    return out.view(np.uint16)
+            out[ks, mt] = dense[16 * mt + (lane & 15), 4 * ks + (lane >> 4), :]
+    hi, lo = split_fp16(out)
+    return hi.view(np.uint16), lo.view(np.uint16)
 
 
 def pack_net(net):
@@ -68,6 +79,7 @@ def pack_net(net):
         raise ValueError("fused net supports n_filters <= %d and <= 4 input planes" % CPAD)
     nb = len(blocks)
     conv_w = np.zeros((2 * nb, KSTEPS, 4, 64, 8), dtype=np.uint16)
+    conv_w_lo = np.zeros_like(conv_w)
     epi = np.zeros((2 * nb, 3, 64), dtype=np.float32)
     epi[:, 1, :] = 1.0
     s_in, t_in = _bn_affine(blocks[0].bn1)
@@ -78,7 +90,7 @@ def pack_net(net):
         s2, t2 = _bn_affine(blk.bn2)
         w1 = blk.conv1.weight.detach().double().numpy() * s2[:, None, None, None]
         b1 = blk.conv1.bias.detach().double().numpy() * s2 + t2
-        conv_w[2 * b] = _pack_conv(w1)
+        conv_w[2 * b], conv_w_lo[2 * b] = _pack_conv(w1)
         epi[2 * b, 0, :F_] = b1
         w2 = blk.conv2.weight.detach().double().numpy()
         b2 = blk.conv2.bias.detach().double().numpy().copy()
@@ -89,7 +101,7 @@ def pack_net(net):
             b2 = b2 + blk.conv3.bias.detach().double().numpy()
         elif b == 0:  # identity skip on block 1 (in_planes == n_filters)
             skip_w[:F_, :cin0] = np.eye(F_, cin0, dtype=np.float32)
-        conv_w[2 * b + 1] = _pack_conv(w2)
+        conv_w[2 * b + 1], conv_w_lo[2 * b + 1] = _pack_conv(w2)
         epi[2 * b + 1, 0, :F_] = b2
         if b + 1 < nb:
             s1, t1 = _bn_affine(blocks[b + 1].bn1)
@@ -103,29 +115,37 @@ def pack_net(net):
     dense = dense.reshape(n_ot * 16, HW * XOUT_C)
     ksteps_fc = HW * XOUT_C // 32
     lane = np.arange(64)
-    fc_w = np.zeros((n_ot, ksteps_fc, 64, 8), dtype=np.float16)
+    fc_w64 = np.zeros((n_ot, ksteps_fc, 64, 8), dtype=np.float64)
     kidx = (32 * np.arange(ksteps_fc)[:, None, None] + 8 * (lane >> 4)[None, :, None] + np.arange(8)[None, None, :])
     for ot in range(n_ot):
         rows = (16 * ot + (lane & 15))[None, :, None]
-        fc_w[ot] = dense[rows, kidx].astype(np.float16)
+        fc_w64[ot] = dense[rows, kidx]
+    fc_w, fc_w_lo = split_fp16(fc_w64)
     fc_b = np.zeros(n_ot * 16, dtype=np.float32)
     fc_b[:A + 1] = net.fc1.bias.detach().numpy()
     return {"conv_w": conv_w, "conv_epi": epi, "in_affine": in_affine, "skip_w": skip_w,
-            "fc_w": fc_w.view(np.uint16), "fc_b": fc_b,
+            "fc_w": fc_w.view(np.uint16), "fc_b": fc_b, "conv_w_lo": conv_w_lo, "fc_w_lo": fc_w_lo.view(np.uint16),
             "rows": H, "cols": W, "in_planes": cin0, "n_filters": F_, "n_blocks": nb, "num_actions": A}
 
 
-def emulate_forward(packed, obs, round_fp16=True):
+def emulate_forward(packed, obs, round_fp16=True, split=False):
     """Numpy restatement of what az_net.hip does with the PACKED buffers (same group/tap/cell maps, same
-    fold, optional fp16 rounding of the MFMA operands) — validates the packing on a CPU-only box."""
+    fold, optional fp16 rounding of the MFMA operands) — validates the packing on a CPU-only box.
+    split=True: the f16x3 path - weights = hi + lo / 2048 from the packed pairs, activations carried as (hi, lo) pairs."""
     H, W, A, nb = packed["rows"], packed["cols"], packed["num_actions"], packed["n_blocks"]
     B = obs.shape[0]
     cells = (H + 2) * (W + 1) + 1
     rnd = (lambda a: a.astype(np.float16).astype(np.float32)) if round_fp16 else (lambda a: a.astype(np.float32))
+    if split:
+        def rnd(a):  # what survives the (hi, lo) representation of an activation
+            hi, lo = split_fp16(a.astype(np.float64))
+            return (hi.astype(np.float64) + lo.astype(np.float64) / SPLIT_SCALE).astype(np.float32)
     lane = np.arange(64)
 
-    def unpack(cw):  # [16,4,64,8] -> dense [co 64][group 64][j 8]
+    def unpack(cw, cw_lo=None):  # [16,4,64,8] -> dense [co 64][group 64][j 8]
         w = cw.view(np.float16).astype(np.float32)
+        if cw_lo is not None:
+            w = (cw.view(np.float16).astype(np.float64) + cw_lo.view(np.float16).astype(np.float64) / SPLIT_SCALE).astype(np.float32)
         dense = np.zeros((64, NGROUPS, 8), dtype=np.float32)
         for ks in range(KSTEPS):
             for mt in range(4):
@@ -145,7 +165,7 @@ def emulate_forward(packed, obs, round_fp16=True):
             a = s_in[None, :v.shape[1]] * v + t_in[None, :v.shape[1]]
             act[:, cell_of(y, x), :v.shape[1]] = rnd(np.where(a > 0, a, LRELU * a))
     for conv in range(2 * nb):
-        dense = unpack(packed["conv_w"][conv])
+        dense = unpack(packed["conv_w"][conv], packed["conv_w_lo"][conv] if split else None)
         acc = np.zeros((B, H * W, 64), dtype=np.float32)
         for y in range(H):
             for x in range(W):
@@ -172,6 +192,9 @@ def emulate_forward(packed, obs, round_fp16=True):
                         act[:, cell_of(y, x), :] = a[:, y * W + x, :CPAD]
     tower = rnd(xres)  # [B][pos][64]
     fcw = packed["fc_w"].view(np.float16).astype(np.float32)  # [ot][ks][lane][8]
+    if split:
+        fcw = (packed["fc_w"].view(np.float16).astype(np.float64)
+               + packed["fc_w_lo"].view(np.float16).astype(np.float64) / SPLIT_SCALE).astype(np.float32)
     n_ot, ksn = fcw.shape[0], fcw.shape[1]
     dense_fc = np.zeros((n_ot * 16, ksn * 32), dtype=np.float32)
     for ot in range(n_ot):
@@ -184,7 +207,9 @@ def emulate_forward(packed, obs, round_fp16=True):
     return e / e.sum(1, keepdims=True), np.tanh(logits[:, A]), tower
 
 
-PRECISIONS = ("f16",)  # MFMA operand formats the library offers (az_net.h)
+# Arithmetic of the matrix products (include/az_net.h): "f16" = fp16 operands, one MFMA per product; "f32x" = fp32-grade,
+# every operand a (hi, lo) pair of fp16 numbers, three MFMAs per product (AZ_NET_PREC_F16X3)
+PRECISIONS = ("f16", "f32x")
 
 
 class FusedNet:
@@ -209,7 +234,11 @@ class FusedNet:
         d.rows, d.cols, d.in_planes = p["rows"], p["cols"], p["in_planes"]
         d.n_filters, d.n_blocks, d.num_actions = p["n_filters"], p["n_blocks"], p["num_actions"]
         d.device = self.device_index
-        self._keep = [np.ascontiguousarray(p[k]) for k in ("conv_w", "conv_epi", "in_affine", "fc_w", "fc_b", "skip_w")]
+        d.precision = _lib.NET_PREC[precision]
+        self._keep = [np.ascontiguousarray(p[k]) for k in ("conv_w", "conv_epi", "in_affine", "fc_w", "fc_b", "skip_w",
+                                                           "conv_w_lo", "fc_w_lo")]
+        d.conv_w_lo = self._keep[6].ctypes.data_as(C.POINTER(C.c_uint16))
+        d.fc_w_lo = self._keep[7].ctypes.data_as(C.POINTER(C.c_uint16))
         d.conv_w = self._keep[0].ctypes.data_as(C.POINTER(C.c_uint16))
         d.conv_epi = self._keep[1].ctypes.data_as(C.POINTER(C.c_float))
         d.in_affine = self._keep[2].ctypes.data_as(C.POINTER(C.c_float))

@@ -22,8 +22,9 @@ Extra objects on the JSON line:
                  measured mean depth / children x sims per tick / HIP-event time of az_engine_advance
   cpu_baseline   the C oracle (same algorithm, sequential playouts, batch-1 torch CPU net — what a reference
                  worker process does) playing FULL games on the host cores: all cores, one thread, and the C1 point
-  reference_precision  the same engine and workload evaluated by fp32 Net.forward (the reference's arithmetic,
-                 network.py:48-64) for a bounded wall time after the timed run: games/s, sims/s, ms per forward
+  reference_precision  the same engine and workload evaluated at the reference's precision (Net.forward is fp32,
+                 network.py:48-64) for a bounded wall time after the timed run: the fused tower's fp32-grade mode
+                 (split-fp16 operands) and, nested as torch_fp32, the torch module in fp32: games/s, sims/s, ms per forward
 """
 import argparse
 import json
@@ -39,7 +40,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "bf16": 2500.0}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "bf16": 2500.0,
+                    "f16x3": 2500.0 / 3}  # fp32-grade mode: three fp16 MFMAs per product
 
 
 def net_flops_per_eval(H, W, A, n_blocks, F0=50, c_in=4):
@@ -154,7 +156,9 @@ def main():
                          "breakthrough 6x6 only): realistic priors, game lengths and tree shapes; overrides --blocks/--filters")
     ap.add_argument("--net", default="fused", choices=["fused", "torch"],
                     help="fused = csrc/az_net.hip MFMA tower (fp16 operands, fp32 accumulate); torch = nn.Module under PyTorch-ROCm")
-    ap.add_argument("--dtype", default=None, choices=["f32", "f16", "bf16"], help="torch backend only (fused is f16)")
+    ap.add_argument("--dtype", default=None, choices=["f32", "f16", "bf16"], help="torch backend only (fused: see --precision)")
+    ap.add_argument("--precision", default="f16", choices=["f16", "f32x"],
+                    help="fused backend: f16 = fp16 MFMA operands (headline); f32x = fp32-grade split-fp16 mode (3 MFMAs per product)")
     ap.add_argument("--check-every", type=int, default=128)
     ap.add_argument("--nodes-per-slot", type=int, default=0, help="node-pool capacity per slot (0 = engine default)")
     ap.add_argument("--max-sims-per-tick", type=int, default=0, help="NN-free playouts a slot may chain per tick (0 = default)")
@@ -210,14 +214,16 @@ def main():
         azdist.broadcast_net(net, src=0)
     if args.net == "fused":
         from alphazero_openspiel_amd.fusednet import FusedNet
-        args.dtype = "f16"
-        evaluator = FusedNet(net.eval(), device, max_boards=G)
+        args.dtype = "f16" if args.precision == "f16" else "f16x3"
+        evaluator = FusedNet(net.eval(), device, max_boards=G, precision=args.precision)
     else:
         args.dtype = args.dtype or "f32"
         tdtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
         evaluator = E.DeviceEvaluator(net, device, dtype=tdtype)
 
-    n_total = (Wm + K + 3) * G
+    # game capacity: warm-up + timed steps + the instrumented pass + the reference-precision legs (bounded by wall time;
+    # at most ~1500 games/s) - a slot that finds no game left goes idle, which would understate those legs
+    n_total = (Wm + K + 2) * G + int(1500 * 1.5 * max(0.0, args.ref_seconds)) + G
     eng = E.SelfPlayEngine(game, G, n_playouts=S, max_games=n_total, device=device, seed=args.seed + 7919 * rank,
                            nodes_per_slot=args.nodes_per_slot, max_sims_per_tick=args.max_sims_per_tick,
                            chain_window_us=args.chain_window_us)
@@ -245,7 +251,7 @@ def main():
     if args.overlap > 1:  # k slot groups, each [advance_slots, forward] on its own stream / graph
         if args.net != "fused":
             raise SystemExit("--overlap needs --net fused")
-        group_nets = [FusedNet(net.eval(), device, max_boards=n) for _, n in E.slot_groups(G, args.overlap)]
+        group_nets = [FusedNet(net.eval(), device, max_boards=n, precision=args.precision) for _, n in E.slot_groups(G, args.overlap)]
         tk = E.OverlappedTicker(eng, group_nets, args.overlap, use_graph=not args.no_graph, io=(obs, pri, val))
         tick, sync_groups, graph = tk.tick, tk.synchronize, (tk.graphs or None)
 
@@ -337,41 +343,64 @@ def main():
         traffic_net = 2 * (5257.5e3 + 11125.5e3) + 21547.2e3 + 128.0e3
         traffic_tree = 4877.7e3 + 5802.6e3
 
-    # ---- reference-precision leg: the SAME engine and workload, evaluated by fp32 Net.forward (network.py:48-64 under
-    # PyTorch-ROCm) instead of the fp16-operand fused tower, for a bounded wall time.  Games finished in the window count.
-    ref_prec = None
-    if world == 1 and args.net == "fused" and args.ref_seconds > 0:
-        ev32 = E.DeviceEvaluator(net, device, dtype=torch.float32)
-        for _ in range(2):  # MIOpen kernel selection / workspace allocation
+    # ---- reference-precision legs: the SAME engine, slots, games in flight and net weights, evaluated at the reference's
+    # precision (Net.forward is fp32, network.py:48-64) for a bounded wall time each.  Games finished in the window count.
+    #   (1) the fused tower in its fp32-grade mode (AZ_NET_PREC_F16X3: split-fp16 operands, fp32 accumulation; error against
+    #       an fp64 evaluation of the order of torch-fp32's own, tests/test_fused_net.py), graph-replayed like the headline;
+    #   (2) the torch module in fp32 under PyTorch-ROCm (MIOpen), eager.
+    def precision_leg(ev, seconds, use_graph):
+        for _ in range(2):  # kernel selection / workspace allocation outside the window (and outside capture)
             eng.advance(pri, val, obs)
-            ev32(obs, pri, val)
+            ev(obs, pri, val)
         torch.cuda.synchronize(device)
-        q0 = eng.progress()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        tr0 = time.perf_counter()
-        n_ticks, fwd_ms = 0, []
-        while time.perf_counter() - tr0 < args.ref_seconds:
-            for _ in range(8):
+        g = None
+        if use_graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
                 eng.advance(pri, val, obs)
-                if n_ticks % 64 == 0:
-                    e0.record()
-                    ev32(obs, pri, val)
-                    e1.record()
-                    e1.synchronize()
-                    fwd_ms.append(e0.elapsed_time(e1))
+                ev(obs, pri, val)
+        fwd_ms = []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            e0.record()
+            ev(obs, pri, val)
+            e1.record()
+            e1.synchronize()
+            fwd_ms.append(e0.elapsed_time(e1))
+        q0 = eng.progress()
+        tr0 = time.perf_counter()
+        n_ticks = 0
+        while time.perf_counter() - tr0 < seconds:
+            for _ in range(64 if use_graph else 8):
+                if g is not None:
+                    g.replay()
                 else:
-                    ev32(obs, pri, val)
+                    eng.advance(pri, val, obs)
+                    ev(obs, pri, val)
                 n_ticks += 1
             torch.cuda.synchronize(device)
         q1 = eng.progress()
         dtr = time.perf_counter() - tr0
-        ref_prec = {"dtype": "f32", "evaluator": "Net.forward fp32 under PyTorch-ROCm (MIOpen), same engine / slots / net weights",
-                    "value": (q1["games_done"] - q0["games_done"]) / dtr, "unit": "games/s",
-                    "sims_per_s": (q1["sims"] - q0["sims"]) / dtr, "evals_per_s": (q1["evals"] - q0["evals"]) / dtr,
-                    "games_counted": q1["games_done"] - q0["games_done"], "ticks": n_ticks, "seconds": dtr,
-                    "ms_per_launch": float(np.median(fwd_ms)),
-                    "tflops": (q1["evals"] - q0["evals"]) / max(1, n_ticks) * f_eval / (float(np.median(fwd_ms)) * 1e-3) / 1e12,
-                    "peak_tflops": MFMA_PEAK_TFLOPS["f32"]}
+        ms = float(np.median(fwd_ms))
+        return {"value": (q1["games_done"] - q0["games_done"]) / dtr, "unit": "games/s",
+                "sims_per_s": (q1["sims"] - q0["sims"]) / dtr, "evals_per_s": (q1["evals"] - q0["evals"]) / dtr,
+                "games_counted": q1["games_done"] - q0["games_done"], "ticks": n_ticks, "seconds": dtr, "ms_per_launch": ms,
+                "tflops": (q1["evals"] - q0["evals"]) / max(1, n_ticks) * f_eval / (ms * 1e-3) / 1e12}
+
+    ref_prec = None
+    if world == 1 and args.net == "fused" and args.precision == "f16" and args.ref_seconds > 0:
+        sync_groups()
+        ev_x3 = FusedNet(net.eval(), device, max_boards=G, precision="f32x")
+        ref_prec = precision_leg(ev_x3, args.ref_seconds, use_graph=not args.no_graph)
+        ref_prec.update({"dtype": "f32-grade (f16x3: every operand a pair of fp16 numbers, 3 MFMAs per product, fp32 accumulate)",
+                         "evaluator": "az_tower_x3_kernel + az_head_kernel<X3> (csrc/az_net.hip), same engine / slots / weights",
+                         "peak_tflops_f16_pipe": MFMA_PEAK_TFLOPS["f16"], "frac_of_f16_peak_issued_x3":
+                         3.0 * ref_prec["tflops"] / MFMA_PEAK_TFLOPS["f16"]})
+        ev32 = E.DeviceEvaluator(net, device, dtype=torch.float32)
+        t32 = precision_leg(ev32, min(10.0, args.ref_seconds), use_graph=False)
+        t32.update({"dtype": "f32", "evaluator": "Net.forward fp32 under PyTorch-ROCm (MIOpen), eager",
+                    "peak_tflops": MFMA_PEAK_TFLOPS["f32"]})
+        ref_prec["torch_fp32"] = t32
 
     if rank == 0:
         plies_per_game = moves_all / max(1.0, games_all)
@@ -386,6 +415,8 @@ def main():
                        "overlap": args.overlap,
                        "weights": ("random-init (torch.manual_seed), eval-mode BN" if args.weights == "random" else
                                    "the reference's shipped checkpoint (5-block x 50)"), "net_backend": args.net,
+                       "net_precision": ("fp16 MFMA operands, fp32 accumulate / residual stream (ExampleGenerator: eval_precision='f16'; "
+                                         "its default is the fp32-grade 'f32x' mode timed in reference_precision)") if args.net == "fused" else args.dtype,
                        "tree_dtype": "f64", "c_puct": 2.5, "temperature": 1.0, "dirichlet_alpha": 0.3,
                        "parallelism": "games sharded over %d GPU(s), no collective inside the search" % world,
                        "hip_graph": graph is not None},

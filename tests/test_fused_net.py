@@ -66,6 +66,26 @@ def test_packing_emulation_matches_torch(tag):
     assert np.abs(ve - v.numpy()[:, 0]).max() <= V_TOL
 
 
+@pytest.mark.parametrize("tag", ["c4_ckpt", "bt6_ckpt", "bt4x5_2block"])
+def test_split_packing_emulation_is_fp32_grade(tag):
+    """The (hi, lo) fp16 pairs of the f16x3 path carry the weights to ~22 bits: the numpy emulation of the kernel's data
+    movement with those pairs agrees with torch fp64 about as well as torch fp32 does."""
+    game, net = _nets()[tag]
+    boards = _random_boards(game, 5, 1)
+    import copy
+    with torch.no_grad():
+        p64, v64 = copy.deepcopy(net).double()(torch.from_numpy(boards).double())
+    packed = fusednet.pack_net(net)
+    pe, ve, _ = fusednet.emulate_forward(packed, boards, split=True)
+    assert np.abs(pe - p64.numpy()).max() <= 3e-6
+    assert np.abs(ve - v64.numpy()[:, 0]).max() <= 3e-6
+    x = np.array([1.0, 0.1, -3.3333333, 1234.567, 1e-3, 1e-5, 3e-8])
+    hi, lo = fusednet.split_fp16(x)
+    back = hi.astype(np.float64) + lo.astype(np.float64) / 2048.0
+    assert np.abs(back[:5] / x[:5] - 1).max() < 2.0 ** -21     # ~22 significant bits in fp16's normal range
+    assert np.abs(back[5:] - x[5:]).max() < 2e-11              # below it (fp16 subnormals) the ABSOLUTE error stays tiny
+
+
 def test_net_matches_reference_golden_outputs():
     """Our Net class + the re-packed shipped checkpoints reproduce the reference Net.forward fixtures."""
     for tag, shape, A in [("connect_four", [3, 6, 7], 7), ("breakthrough6", [3, 6, 6], 432)]:
@@ -108,6 +128,51 @@ def test_fused_forward_matches_torch(tag, n):
     pf2, vf2 = fn.forward(obs[: max(1, n // 2)].contiguous())
     torch.cuda.synchronize()
     assert np.abs(pf2.cpu().numpy() - pf[: max(1, n // 2)]).max() < 1e-6
+    fn.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,n", [("c4_ckpt", 157), ("c4_10block", 4096), ("bt6_ckpt", 40), ("bt6_10block", 1000),
+                                   ("bt8_2block", 37), ("bt8_20block", 256), ("bt5x4_3block", 50), ("bt4x5_2block", 130),
+                                   ("c4_56f_2block", 33)])
+def test_fused_f32x_forward_is_fp32_grade(tag, n):
+    """precision="f32x" (AZ_NET_PREC_F16X3: split-fp16 operands, three MFMAs per product) against an fp64 evaluation of
+    the same net: the error must be of the order of torch-fp32's own error against fp64 - i.e. the path is a stand-in
+    for the reference's fp32 Net.forward (network.py:48-64), not a reduced-precision approximation of it."""
+    import copy
+    game, net = _nets()[tag]
+    boards = _random_boards(game, n, 7)
+    with torch.no_grad():
+        p32, v32 = net(torch.from_numpy(boards))
+        p64, v64 = copy.deepcopy(net).double()(torch.from_numpy(boards).double())
+    p64, v64 = p64.numpy(), v64.numpy()[:, 0]
+    e32 = max(np.abs(p32.numpy() - p64).max(), np.abs(v32.numpy()[:, 0] - v64).max())
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=max(n, 16), precision="f32x")
+    pf, vf = fn.forward(torch.from_numpy(boards).cuda())
+    torch.cuda.synchronize()
+    pf, vf = pf.cpu().numpy().astype(np.float64), vf.cpu().numpy().astype(np.float64)
+    assert np.isfinite(pf).all() and np.isfinite(vf).all() and np.abs(pf.sum(1) - 1).max() < 1e-5
+    ex = max(np.abs(pf - p64).max(), np.abs(vf - v64).max())
+    print("f32x %s n=%d: max err vs fp64 %.3g (torch fp32: %.3g)" % (tag, n, ex, e32))
+    assert ex <= max(4.0 * e32, 2e-6), (ex, e32)
+    if n <= 40:
+        _, _, tower = fusednet.emulate_forward(fn.packed, boards, split=True)
+        got = fn.read_tower(n)
+        assert np.abs(got - tower).max() / (np.abs(tower).max() + 1e-6) < 2e-5
+    fn.close()
+
+
+@pytest.mark.gpu
+def test_fused_f32x_outputs_do_not_depend_on_the_batch_size():
+    game, net = _nets()["c4_10block"]
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=1024, precision="f32x")
+    torch.manual_seed(5)
+    obs = (torch.rand(1024, 4, 6, 7, device="cuda") > 0.5).float()
+    ref_p, ref_v = [t.clone() for t in fn.forward(obs)]
+    for n in (512, 300, 64, 5):
+        p, v = fn.forward(obs[:n].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(p, ref_p[:n]) and torch.equal(v, ref_v[:n]), n
     fn.close()
 
 

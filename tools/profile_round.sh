@@ -6,11 +6,11 @@ export TMPDIR=/tmp
 OUT=${1:-gpurun_out/prof}
 B="bench.py --cpu-baseline off --ref-seconds 0 --steps 1 --warmup 0"
 rocprofv3 -L > $OUT.counters.txt 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/trace -- python3 bench.py --cpu-baseline off --ref-seconds 0 > $OUT.trace_bench.json 2> $OUT.trace.err
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/sq1 -- python3 $B > $OUT.sq1.json 2> $OUT.sq1.err
-rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU -d $OUT/sq2 -- python3 $B > $OUT.sq2.json 2> $OUT.sq2.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- python3 $B > $OUT.fetch.json 2> $OUT.fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- python3 $B > $OUT.write.json 2> $OUT.write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-baseline off --ref-seconds 0 > $OUT.trace_bench.json 2> $OUT.trace.err
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/sq1 -- python3 $B > $OUT.sq1.json 2> $OUT.sq1.err
+rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU -d $OUT/sq2 -- python3 $B > $OUT.sq2.json 2> $OUT.sq2.err
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -- python3 $B > $OUT.fetch.json 2> $OUT.fetch.err
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -- python3 $B > $OUT.write.json 2> $OUT.write.err
 python3 tools/pmc_summary.py $OUT/trace $OUT/sq1 $OUT/sq2 $OUT/fetch $OUT/write > $OUT.summary.txt 2>&1
 rm -rf $OUT/sq1 $OUT/sq2 $OUT/fetch $OUT/write   # raw per-dispatch CSVs are large; the summary is what is kept
 find $OUT/trace -name "*.csv" ! -name "*kernel_stats.csv" -delete
