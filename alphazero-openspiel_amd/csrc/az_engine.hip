@@ -379,6 +379,37 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, i
     }
 }
 
+// The slot's game is over: publish its length and result, take the next game id of the generation (device counter).
+// Returns false when no game is left (the slot is stored idle).
+__device__ __forceinline__ bool finish_game_take_next(const Params &p, int g, int lane, SlotRegs &sr, float ret0,
+                                                      unsigned long long st_moves) {
+    unsigned long long nxt = 0;
+    if (lane == 0) {
+        p.rec_len[sr.gid] = sr.rs.ply - p.start.ply;
+        p.rec_ret0[sr.gid] = ret0;
+        __threadfence(); // records before the done-count
+        atomicAdd(p.games_done, 1ull);
+        nxt = atomicAdd(p.next_game, 1ull);
+    }
+    nxt = ((unsigned long long)rflu((uint32_t)(nxt >> 32)) << 32) | rflu((uint32_t)nxt);
+    if ((long long)nxt >= p.n_games) {
+        sr.gid = -1;
+        if (lane == 0) {
+            slot_store(p, g, sr, PH_IDLE);
+            p.stats[(size_t)g * ST_N + ST_MOVES] += st_moves;
+        }
+        return false;
+    }
+    sr.gid = (int)nxt;
+    sr.rs = p.start;
+    sr.sims = 0;
+    return true;
+}
+// arena: the agent plays side gid & 1; is it the OPPONENT's turn in state s of game gid?
+__device__ __forceinline__ bool opponent_to_move(const Params &p, int gid, const AzState &s) {
+    return p.arena_agent != AZ_ARENA_SELF_PLAY && ((s.ply ^ gid) & 1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The cold path of a tick: AlphaZeroBot.step's tail + play_game_self's loop body for a slot whose S playouts are
 // done (phase PH_MOVE, set by the previous tick), game turnover, and the root-evaluation request of the next search.
@@ -393,6 +424,36 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
     unsigned long long st_moves = 0, st_evals = 0, st_compact = 0;
     unsigned int fault = 0;
 
+    if (ph == PH_OPP_DONE) { // arena: apply the move the opponent bot chose; the agent's tree follows it (alphazerobot.py:60-64)
+        const int action = rfl(p.opp_action[g]);
+        uint32_t c0 = rflu(t.nd[sr.root].C0);
+        int nc = c0 == NONE32 ? 0 : (int)(rflu(t.nd[sr.root].META) >> 16);
+        int cact = lane < nc ? (int)(t.nd[c0 + lane].META & 0xFFFFu) : -1;
+        unsigned long long hit = __ballot(cact == action);
+        const int sel = (p.keep_tree && hit) ? __ffsll(hit) - 1 : -1;
+        if (sr.rs.ply >= p.max_plies || sr.gid >= p.max_games || sr.gid < 0) fault |= AZ_FAULT_PLY_OVERFLOW;
+        else if (lane == 0) { // the ply is recorded (state, move; no search statistics: n_children = 0)
+            size_t ri = (size_t)sr.gid * p.max_plies + sr.rs.ply;
+            p.rec_states[ri * 2] = sr.rs.bb0;
+            p.rec_states[ri * 2 + 1] = sr.rs.bb1;
+            p.rec_move[ri] = (uint16_t)action;
+            p.rec_nchild[ri] = 0;
+            p.rec_value[ri] = 0.0;
+        }
+        float ret0 = 0.f;
+        int term = fault ? 0 : az_apply<GAME>(sr.rs, geom, action, &ret0);
+        sr.sims = 0;
+        if (fault) {
+            ph = PH_IDLE;
+        } else if (term) {
+            if (!finish_game_take_next(p, g, lane, sr, ret0, 0)) return;
+            reroot(p, g, sr, t, -1, lane, fault, st_compact);
+            ph = opponent_to_move(p, sr.gid, sr.rs) ? PH_OPPONENT : (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN);
+        } else {
+            reroot(p, g, sr, t, sel, lane, fault, st_compact);
+            ph = p.use_dirichlet ? PH_NEED_ROOT : PH_RUN;
+        }
+    }
     if (ph == PH_MOVE) {
         if (p.manual_moves) {
             if (lane == 0) p.phase[g] = PH_SEARCH_DONE;
@@ -409,7 +470,7 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
             cact = (int)(t.nd[c0 + lane].META & 0xFFFFu);
         }
         long long tot = wave_sum_ll((long long)cn);
-        if (nc == 0 || tot <= 0) fault |= AZ_FAULT_NO_VISITS;
+        if (nc == 0 || (tot <= 0 && p.arena_agent != AZ_ARENA_NET)) fault |= AZ_FAULT_NO_VISITS;
         if (sr.rs.ply >= p.max_plies || sr.gid >= p.max_games || sr.gid < 0) fault |= AZ_FAULT_PLY_OVERFLOW;
         if (fault) {
             if (lane == 0) {
@@ -454,7 +515,7 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
             target = value * mult;
         }
         // action sampling: visit fractions -> remove_illegal_actions -> temperature -> np.random.choice
-        double nv = lane < nc ? (double)cn / (double)tot : 0.0; // mcts.py:162
+        double nv = (lane < nc && tot > 0) ? (double)cn / (double)tot : 0.0; // mcts.py:162
         double ssum = np_sum_sparse(p.pw, nv, cact, nc);        // alphazerobot.py:13
         if (ssum > 1e-6) nv = nv / ssum; else nv = lane < nc ? 1.0 / (double)nc : 0.0;
         double ap = lane < nc ? np_pow(nv, p.inv_temp) : 0.0; // alphazerobot.py:78
@@ -477,6 +538,18 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         unsigned long long gt = __ballot(lane < nc && mycdf > u);
         int sel = gt ? __ffsll(gt) - 1 : nc - 1;
         while (sel > 0 && __shfl(cn, sel) == 0) sel--; // rounding corner: never pick an unvisited child
+        if (p.arena_agent == AZ_ARENA_ZERO) { // outside self-play the bot is greedy: np.argmax of the tempered visit fractions
+                                              // (alphazerobot.py:86-91) = the first most-visited child
+            double mx = wave_max(lane < nc ? ap : -INFINITY);
+            sel = __ffsll((unsigned long long)__ballot(lane < nc && ap == mx)) - 1;
+        } else if (p.arena_agent == AZ_ARENA_NET) { // NeuralNetBot.step (alphazerobot.py:105-120): argmax of the masked,
+                                                    // renormalised network priors; the children hold them after the root expansion
+            double pv = lane < nc ? t.nd[c0 + lane].P : 0.0;
+            double ps = np_sum_sparse(p.pw, pv, cact, nc);
+            if (ps > 1e-6) pv = pv / ps; else pv = lane < nc ? 1.0 / (double)nc : 0.0;
+            double mx = wave_max(lane < nc ? pv : -INFINITY);
+            sel = __ffsll((unsigned long long)__ballot(lane < nc && pv == mx)) - 1;
+        }
         int action = rfl(__shfl(cact, sel));
         // the example record (game_utils.py:169): state + root child visits; pi = N/sum is formed on the host
         size_t ri = (size_t)sr.gid * p.max_plies + sr.rs.ply;
@@ -496,30 +569,12 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         int term = az_apply<GAME>(sr.rs, geom, action, &ret0); // game_utils.py:197
         sr.sims = 0;
         if (term) {
-            unsigned long long nxt = 0;
-            if (lane == 0) {
-                p.rec_len[sr.gid] = sr.rs.ply - p.start.ply;
-                p.rec_ret0[sr.gid] = ret0;
-                __threadfence(); // records before the done-count
-                atomicAdd(p.games_done, 1ull);
-                nxt = atomicAdd(p.next_game, 1ull);
-            }
-            nxt = ((unsigned long long)rflu((uint32_t)(nxt >> 32)) << 32) | rflu((uint32_t)nxt);
-            if ((long long)nxt >= p.n_games) {
-                sr.gid = -1;
-                if (lane == 0) {
-                    slot_store(p, g, sr, PH_IDLE);
-                    p.stats[(size_t)g * ST_N + ST_MOVES] += st_moves;
-                }
-                return;
-            }
-            sr.gid = (int)nxt;
-            sr.rs = p.start;
+            if (!finish_game_take_next(p, g, lane, sr, ret0, st_moves)) return;
             reroot(p, g, sr, t, -1, lane, fault, st_compact);
         } else {
             reroot(p, g, sr, t, p.keep_tree ? sel : -1, lane, fault, st_compact);
         }
-        ph = p.use_dirichlet ? PH_NEED_ROOT : PH_RUN;
+        ph = opponent_to_move(p, sr.gid, sr.rs) ? PH_OPPONENT : (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN);
     }
     if (ph == PH_NEED_ROOT) { // expand_root_dirichlet's policy_fn(state) (mcts.py:183)
         if (p.rng_mode == AZ_RNG_PHILOX) { // np.random.dirichlet(0.3 * ones(n_legal)) (mcts.py:187): gamma draws / their sum
@@ -572,7 +627,8 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
     const float value_raw = values ? values[g] : 0.f;
     slot_load(p, g, sr);
     const int ph = rfl(ph_raw);
-    if (ph == PH_MOVE || ph == PH_NEED_ROOT) { // the agent's move / the next search's root request: ends this slot's tick
+    if (ph == PH_MOVE || ph == PH_NEED_ROOT || ph == PH_OPP_DONE) { // the agent's move / the opponent's move / the next search's
+                                                                    // root request: ends this slot's tick
         move_step<GAME>(p, g, lane, ph, sr, obs_out);
         return;
     }
@@ -786,6 +842,118 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Arena opponents (evaluation games, game_utils.py:16-145): ONE THREAD per slot whose opponent is to move.
+//  * AZ_OPPONENT_RANDOM - pyspiel.make_uniform_random_bot: a uniformly random legal action.
+//  * AZ_OPPONENT_UCT    - open_spiel.python.algorithms.mcts.MCTSBot(game, player, uct_c, max_search_nodes,
+//    RandomRolloutEvaluator(1)).  OpenSpiel is a third-party dependency absent from the reference tree and unpinned
+//    (SURVEY.md 8(c)); this restates the published algorithm: per simulation descend from the root while the node has
+//    been visited (children are created the first time a visited node is descended through), choosing the child that
+//    maximises  total_reward / explore_count + uct_c * sqrt(log(parent explore_count) / explore_count)  (an unvisited
+//    child counts as +infinity; ties -> first in legal-action order), evaluate the reached node by ONE uniformly random
+//    rollout to the end of the game (terminal nodes by their return), add the result to every node of the path as seen
+//    by the player who moved into it; finally play the most visited root child (ties -> first).
+// Random numbers: Philox stream (seed, game id, ply, purpose 2), consumed in simulation order, so that the C restatement
+// in oracle/az_oracle.c reproduces every move bit for bit.
+template <int GAME> __device__ int uct_search(const Params &p, int g, const AzState &root_s, Philox &r) {
+    const AzGeom &geom = p.geom;
+    uint32_t *N = p.uct_N + (size_t)g * p.uct_cap, *C0 = p.uct_C0 + (size_t)g * p.uct_cap, *META = p.uct_META + (size_t)g * p.uct_cap;
+    double *W = p.uct_W + (size_t)g * p.uct_cap;
+    uint32_t alloc = 1;
+    N[0] = 0;
+    W[0] = 0.0;
+    C0[0] = NONE32;
+    META[0] = 0;
+    const int root_player = root_s.ply & 1;
+    uint32_t path[192];
+    for (int sim = 0; sim < p.opp_sims; sim++) {
+        AzState s = root_s;
+        uint32_t node = 0;
+        int term = 0, depth = 0;
+        float ret0 = 0.f;
+        path[0] = 0;
+        while (!term && N[node] > 0) {
+            if (C0[node] == NONE32) { // first descent through a visited node: create its children
+                const int n = az_count_legal<GAME>(s, geom);
+                if (alloc + (uint32_t)n > p.uct_cap) return -1;
+                C0[node] = alloc;
+                META[node] = (META[node] & 0xFFFFu) | ((uint32_t)n << 16);
+                for (int k = 0; k < n; k++) {
+                    N[alloc + k] = 0;
+                    W[alloc + k] = 0.0;
+                    C0[alloc + k] = NONE32;
+                    META[alloc + k] = (uint32_t)az_nth_legal<GAME>(s, geom, k);
+                }
+                alloc += (uint32_t)n;
+            }
+            const uint32_t c0 = C0[node];
+            const int nc = (int)(META[node] >> 16);
+            const double L = p.log_table[N[node]];
+            double best = -INFINITY;
+            int bi = 0;
+            for (int k = 0; k < nc; k++) {
+                const uint32_t cn = N[c0 + k];
+                const double v = cn == 0 ? INFINITY : W[c0 + k] / (double)cn + p.opp_c * sqrt(L / (double)cn);
+                if (v > best) {
+                    best = v;
+                    bi = k;
+                }
+            }
+            node = c0 + (uint32_t)bi;
+            term = az_apply<GAME>(s, geom, (int)(META[node] & 0xFFFFu), &ret0);
+            path[++depth] = node;
+        }
+        while (!term) { // RandomRolloutEvaluator(1): uniformly random legal actions to the end of the game
+            const int n = az_count_legal<GAME>(s, geom);
+            int k = (int)(philox_u01(r) * (double)n);
+            k = k < n ? k : n - 1;
+            term = az_apply<GAME>(s, geom, az_nth_legal<GAME>(s, geom, k), &ret0);
+        }
+        for (int d = 0; d <= depth; d++) { // the node at depth d was entered by player (root_player + d + 1) & 1
+            const int mover = (root_player + d + 1) & 1;
+            N[path[d]] += 1;
+            W[path[d]] += mover == 0 ? (double)ret0 : -(double)ret0;
+        }
+    }
+    if (C0[0] == NONE32) return -1;
+    const uint32_t c0 = C0[0];
+    const int nc = (int)(META[0] >> 16);
+    uint32_t bn = 0;
+    int bi = 0;
+    for (int k = 0; k < nc; k++)
+        if (k == 0 || N[c0 + k] > bn) {
+            bn = N[c0 + k];
+            bi = k;
+        }
+    return (int)(META[c0 + bi] & 0xFFFFu);
+}
+
+template <int GAME> __global__ __launch_bounds__(64) void az_opponent_kernel(Params p) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.G || p.phase[g] != PH_OPPONENT) return;
+    AzState s;
+    s.bb0 = p.bb0[g];
+    s.bb1 = p.bb1[g];
+    s.ply = p.ply[g];
+    Philox r;
+    philox_init(r, p.seed, (uint32_t)p.gid[g], (uint32_t)s.ply, 2u, 0u);
+    int action;
+    if (p.opp_kind == AZ_OPPONENT_RANDOM) {
+        const int n = az_count_legal<GAME>(s, p.geom);
+        int k = (int)(philox_u01(r) * (double)n);
+        action = az_nth_legal<GAME>(s, p.geom, k < n ? k : n - 1);
+    } else {
+        action = uct_search<GAME>(p, g, s, r);
+    }
+    if (action < 0) {
+        atomicOr(p.faults, AZ_FAULT_POOL_EXHAUSTED);
+        p.phase[g] = PH_IDLE;
+        return;
+    }
+    p.opp_action[g] = action;
+    p.phase[g] = PH_OPP_DONE;
+}
+
 // MCTS.update_root for manual_moves engines (AlphaZeroBot.step outside the self-play loop).
 template <int GAME>
 __global__ __launch_bounds__(256) void az_update_root_kernel(Params p, const int *__restrict__ actions, int keep_subtree) {
@@ -842,7 +1010,9 @@ __global__ void az_reset_kernel(Params p) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= p.G) return;
     bool active = (long long)g < p.n_games;
-    p.phase[g] = active ? (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN) : PH_IDLE;
+    p.phase[g] = !active ? PH_IDLE
+                 : ((p.arena_agent != AZ_ARENA_SELF_PLAY && ((p.start.ply ^ g) & 1)) ? PH_OPPONENT
+                                                                                       : (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN));
     p.gid[g] = active ? g : -1;
     p.bb0[g] = p.start.bb0;
     p.bb1[g] = p.start.bb1;
@@ -946,7 +1116,16 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
         g_create_err = "n_slots, n_playouts, max_games must be >= 1; temperature > 0; c_puct >= 0";
         return AZ_E_INVALID;
     }
-    if (!c.use_dirichlet && c.n_playouts < 2) {
+    if (c.arena_agent < AZ_ARENA_SELF_PLAY || c.arena_agent > AZ_ARENA_NET ||
+        (c.arena_agent != AZ_ARENA_SELF_PLAY && (c.arena_opponent != AZ_OPPONENT_RANDOM && c.arena_opponent != AZ_OPPONENT_UCT)) ||
+        (c.arena_agent == AZ_ARENA_SELF_PLAY && c.arena_opponent != AZ_OPPONENT_NONE) ||
+        (c.arena_opponent == AZ_OPPONENT_UCT && (c.opponent_sims < 2 || c.opponent_sims > 100000 || !(c.opponent_uct_c >= 0.0))) ||
+        (c.arena_agent != AZ_ARENA_SELF_PLAY && (c.manual_moves || c.rng_mode != AZ_RNG_PHILOX))) {
+        g_create_err = "bad arena configuration (agent 0..2; an arena needs opponent RANDOM or UCT with 2 <= opponent_sims, "
+                       "rng_mode PHILOX, manual_moves 0)";
+        return AZ_E_INVALID;
+    }
+    if (!c.use_dirichlet && c.n_playouts < 2 && c.arena_agent != AZ_ARENA_NET) {
         g_create_err = "n_playouts must be >= 2 without root Dirichlet expansion (mcts.py:162 divides by zero)";
         return AZ_E_INVALID;
     }
@@ -991,6 +1170,11 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     p.max_sims_per_tick = c.max_sims_per_tick > 0 ? c.max_sims_per_tick : 6;
     p.chain_clocks = c.chain_window_us < 0 ? 0 : (c.chain_window_us > 0 ? c.chain_window_us : 10) * 100;
     p.manual_moves = c.manual_moves ? 1 : 0;
+    p.arena_agent = c.arena_agent;
+    p.opp_kind = c.arena_opponent;
+    p.opp_sims = c.opponent_sims;
+    p.opp_c = c.opponent_uct_c;
+    p.uct_cap = c.arena_opponent == AZ_OPPONENT_UCT ? (uint32_t)(1 + (size_t)c.opponent_sims * p.maxc) : 0;
     p.need_per_move = (uint32_t)((c.n_playouts + 1) * p.maxc);
     // default pool: room for 48 searches, or for the whole game if it is shorter (connect_four: 42 plies -> a slot never
     // compacts; every compaction is a ~100-400 us single-wave Cheney copy that holds the whole launch), capped so that the
@@ -1043,6 +1227,12 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     DA(p.bb0, G); DA(p.bb1, G); DA(p.leaf_bb0, G); DA(p.leaf_bb1, G);
     DA(p.stats, G * ST_N); DA(p.eta_buf, G * p.maxc);
     DA(p.next_game, 1); DA(p.games_done, 1); DA(p.faults, 1);
+    if (c.arena_agent != AZ_ARENA_SELF_PLAY) DA(p.opp_action, G);
+    double *d_log = nullptr;
+    if (p.uct_cap) {
+        DA(p.uct_N, G * p.uct_cap); DA(p.uct_C0, G * p.uct_cap); DA(p.uct_META, G * p.uct_cap); DA(p.uct_W, G * p.uct_cap);
+        DA(d_log, (size_t)c.opponent_sims + 2);
+    }
     DA(p.rec_len, (size_t)c.max_games); DA(p.rec_ret0, (size_t)c.max_games);
     DA(p.rec_states, plies * 2); DA(p.rec_move, plies); DA(p.rec_nchild, plies);
     DA(p.rec_child_action, plies * p.maxc); DA(p.rec_child_visits, plies * p.maxc); DA(p.rec_value, plies);
@@ -1054,6 +1244,12 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     }
     (void)hipMemset(p.phase, 0, G * sizeof(int));
     (void)hipMemset(p.path, 0, G * p.pstride * sizeof(uint32_t));
+    if (d_log) { // log(n) from the host's libm: the UCT values then agree bit for bit with the CPU restatement
+        std::vector<double> lt((size_t)c.opponent_sims + 2, 0.0);
+        for (size_t i = 1; i < lt.size(); i++) lt[i] = log((double)i);
+        (void)hipMemcpy(d_log, lt.data(), lt.size() * sizeof(double), hipMemcpyHostToDevice);
+        p.log_table = d_log;
+    }
     *out = e;
     return AZ_OK;
 }
@@ -1195,6 +1391,24 @@ extern "C" int az_engine_advance_slots(az_engine *e, int32_t first_slot, int32_t
     rc = advance_range(e, first_slot, first_slot + n_slots, priors, values, obs_out, stream);
     if (rc == AZ_OK) e->ticks++;
     return rc;
+}
+
+extern "C" int az_engine_opponent_moves(az_engine *e, void *stream) {
+    if (!e) return AZ_E_INVALID;
+    if (e->p.arena_agent == AZ_ARENA_SELF_PLAY) {
+        e->err = "az_engine_opponent_moves needs an engine created with arena_agent / arena_opponent";
+        return AZ_E_STATE;
+    }
+    if (!e->reset_done) {
+        e->err = "az_engine_opponent_moves before az_engine_reset";
+        return AZ_E_STATE;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    dim3 grid((e->p.G + 63) / 64), block(64);
+    if (e->cfg.game == AZ_GAME_CONNECT_FOUR) hipLaunchKernelGGL((az_opponent_kernel<AZG_CONNECT_FOUR>), grid, block, 0, (hipStream_t)stream, e->p);
+    else hipLaunchKernelGGL((az_opponent_kernel<AZG_BREAKTHROUGH>), grid, block, 0, (hipStream_t)stream, e->p);
+    HIPCHK(e, hipGetLastError());
+    return AZ_OK;
 }
 
 extern "C" int az_engine_update_root(az_engine *e, const int32_t *actions, int32_t keep_subtree, void *stream) {

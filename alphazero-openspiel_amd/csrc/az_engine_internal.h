@@ -11,7 +11,8 @@
 
 #define NONE32 0xFFFFFFFFu
 
-enum { PH_IDLE = 0, PH_RUN = 1, PH_MOVE = 2, PH_WAIT_ROOT = 3, PH_WAIT_LEAF = 4, PH_SEARCH_DONE = 5, PH_NEED_ROOT = 6 };
+enum { PH_IDLE = 0, PH_RUN = 1, PH_MOVE = 2, PH_WAIT_ROOT = 3, PH_WAIT_LEAF = 4, PH_SEARCH_DONE = 5, PH_NEED_ROOT = 6,
+       PH_OPPONENT = 7 /* arena: the opponent bot is to move */, PH_OPP_DONE = 8 /* ... and has chosen (opp_action) */ };
 enum { ST_MOVES = 0, ST_SIMS, ST_EVALS, ST_TERM, ST_DEPTH, ST_CHILDREN, ST_NODES, ST_COMPACT, ST_N };
 
 // One search-tree node (mcts.py:10-20 Node: N, Q, P, children).  32 bytes, so a block of sibling nodes is one
@@ -55,6 +56,14 @@ struct Params {
     // injected randomness
     const double *etas, *us;
     double *eta_buf; // [G][maxc] Dirichlet draw staged with the root request (Philox mode)
+    // arena (evaluation games against a bot)
+    int arena_agent, opp_kind, opp_sims;
+    double opp_c;
+    int *opp_action;           // [G] the opponent bot's chosen move
+    uint32_t uct_cap;          // UCT opponent: nodes per slot
+    uint32_t *uct_N, *uct_C0, *uct_META; // [G][uct_cap] explore_count, first child, action | n_children << 16
+    double *uct_W;             // [G][uct_cap] total_reward, seen by the player who moved into the node
+    const double *log_table;   // [opp_sims + 2] log(n) computed on the host (glibc), so that host and device agree bit for bit
     // records
     int *rec_len;
     float *rec_ret0;

@@ -164,6 +164,45 @@ template <int GAME> AZ_HD int az_apply(AzState &s, const AzGeom &g, int action, 
     }
 }
 
+// Scalar (one thread = one state) legal-action helpers, ascending action order = OpenSpiel's legal_actions() order.
+// Used by the arena's opponent bots (random rollouts), where a thread owns a whole game.
+template <int GAME> AZ_HD int az_count_legal(const AzState &s, const AzGeom &g) {
+    if (GAME == AZG_CONNECT_FOUR) return az_popc64((uint64_t)az_c4_legal_mask(s));
+    int me = s.ply & 1, n = 0;
+    uint64_t own = me ? s.bb1 : s.bb0;
+    while (own) {
+        int cell = az_popc64((own & (0 - own)) - 1);
+        own &= own - 1;
+        n += az_popc64((uint64_t)(az_bt_cell_moves(s, g, cell) & 7u));
+    }
+    return n;
+}
+// the n-th (0-based) legal action in ascending order; n must be < az_count_legal
+template <int GAME> AZ_HD int az_nth_legal(const AzState &s, const AzGeom &g, int n) {
+    if (GAME == AZG_CONNECT_FOUR) {
+        uint32_t m = az_c4_legal_mask(s);
+        for (int c = 0; c < 7; c++)
+            if ((m >> c) & 1u) {
+                if (n == 0) return c;
+                n--;
+            }
+        return -1;
+    }
+    int me = s.ply & 1;
+    uint64_t own = me ? s.bb1 : s.bb0;
+    while (own) {
+        int cell = az_popc64((own & (0 - own)) - 1);
+        own &= own - 1;
+        uint32_t mv = az_bt_cell_moves(s, g, cell);
+        for (int d = 0; d < 3; d++)
+            if (mv & (1u << d)) {
+                if (n == 0) return az_bt_encode(cell, me, d, (mv >> (4 + d)) & 1u);
+                n--;
+            }
+    }
+    return -1;
+}
+
 // Observation element idx of state_to_board's (C+1,H,W) tensor (network.py:9-18), C = 3.
 //   connect_four planes: 0 empty, 1 player-1 stones, 2 player-0 stones, 3 current player
 //   breakthrough planes: 0 black,  1 white,          2 empty,           3 current player

@@ -100,6 +100,18 @@ def all_gather_device_exports(buf):
     return out.to(buf.device)
 
 
+def all_reduce_sum(t, device=None):
+    """Sum a small CPU tensor over the ranks (on the rank's GPU when the backend is nccl)."""
+    if world_size() == 1:
+        return t
+    if dist.get_backend() == "nccl":
+        d = t.to(device)
+        dist.all_reduce(d)
+        return d.cpu()
+    dist.all_reduce(t)
+    return t
+
+
 def broadcast_net(net, src=0):
     """Weights + BN buffers from the training rank to every self-play rank at generation start
     (replaces the deepcopy handed to each handle_gpu process, reference examplegenerator.py:121).  One flat fp32

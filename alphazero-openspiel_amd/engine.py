@@ -36,7 +36,7 @@ class SelfPlayEngine:
     def __init__(self, game_name, n_slots, n_playouts=100, c_puct=2.5, temperature=1.0, dirichlet_ratio=0.25,
                  use_dirichlet=True, keep_search_tree=True, backup="on-policy", max_games=None, device=0,
                  rng="philox", seed=0, nodes_per_slot=0, max_sims_per_tick=0, chain_window_us=0, manual_moves=False,
-                 dirichlet_alpha=0.3):
+                 dirichlet_alpha=0.3, arena_agent=None, opponent=None, opponent_sims=0, opponent_uct_c=1.0):
         self.lib = _lib.load()
         self.game = Game(game_name) if isinstance(game_name, str) else game_name
         self.device_index = _device_index(device)
@@ -63,6 +63,11 @@ class SelfPlayEngine:
         cfg.dirichlet_alpha = float(dirichlet_alpha)
         cfg.temperature = float(temperature)
         cfg.seed = int(seed) & (2 ** 64 - 1)
+        # evaluation arena (alphazero_openspiel_amd.arena): agent "zero" | "net" against opponent "random" | "uct"
+        cfg.arena_agent = _lib.ARENA_AGENTS[arena_agent]
+        cfg.arena_opponent = _lib.OPPONENTS[opponent]
+        cfg.opponent_sims = int(opponent_sims)
+        cfg.opponent_uct_c = float(opponent_uct_c)
         self.cfg = cfg
         self.backup = backup
         self._h = C.c_void_p()
@@ -151,6 +156,10 @@ class SelfPlayEngine:
         self._check(self.lib.az_engine_advance_slots(self._h, int(first_slot), int(n_slots),
                                                      self._ptr(priors, (self.G, self.A)), self._ptr(values, (self.G,)),
                                                      self._ptr(obs, (self.G,) + self.obs_shape), self._stream()))
+
+    def opponent_moves(self):
+        """Arena engines: let the opponent bot choose its move in every slot where it is to move (applied by the next advance)."""
+        self._check(self.lib.az_engine_opponent_moves(self._h, self._stream()))
 
     def update_root(self, actions, keep_subtree=True):
         arr = (C.c_int32 * self.G)(*[int(a) for a in actions])

@@ -23,10 +23,13 @@ _ENGINE_KW = ("n_playouts", "c_puct", "temperature", "dirichlet_ratio", "use_dir
 
 class ExampleGenerator:
     def __init__(self, net, game_name, device, n_pools=1, n_processes=1, **kwargs):
-        if kwargs.get("is_test") or kwargs.get("net2") is not None:
-            raise NotImplementedError("the evaluation-arena branches (is_test / net2 / generate_tests, "
-                                      "reference examplegenerator.py:88-90,100-103,177-195) are outside the "
-                                      "self-play hot path this package replaces")
+        if kwargs.get("net2") is not None:
+            raise NotImplementedError("two-network pairings (net2 / test_zero_vs_zero, reference examplegenerator.py:88-90, "
+                                      "game_utils.py:120-145) are tournament tooling outside the path this package replaces")
+        self.is_test = bool(kwargs.get("is_test", False))
+        self.generate_statistics = bool(kwargs.get("generate_statistics", False))
+        if self.generate_statistics:
+            raise NotImplementedError("generate_statistics deep-copies search trees per move (game_utils.py:30-31): not built")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise EngineError("ExampleGenerator needs a HIP device: self-play runs in HIP kernels, there is no "
@@ -111,4 +114,30 @@ class ExampleGenerator:
         return n_local * world
 
     def generate_tests(self, n_games, game_fn, n_playouts_mcts):
-        raise NotImplementedError("evaluation arenas are outside the self-play hot path (see __init__)")
+        """n_games calls of `game_fn` (test_zero_vs_mcts / test_net_vs_mcts / test_zero_vs_random / test_net_vs_random:
+        two games each, the agent once as first and once as second player) against an MCTSBot with n_playouts_mcts
+        simulations -> average reward sum(score1 + score2) / (2 n_games) (examplegenerator.py:177-195).  All 2 n_games
+        games are slots of one device arena (alphazero_openspiel_amd.arena); with torch.distributed the tests shard over
+        the ranks and the mean is all-reduced."""
+        from . import arena
+        name = getattr(game_fn, "__name__", str(game_fn))
+        pairing = {"test_zero_vs_mcts": ("zero", "uct"), "test_net_vs_mcts": ("net", "uct"),
+                   "test_zero_vs_random": ("zero", "random"), "test_net_vs_random": ("net", "random")}.get(name)
+        if pairing is None:
+            raise NotImplementedError("generate_tests supports the one-network pairings of game_utils.py:53-117, got %s" % name)
+        world, rank = azdist.world_size(), azdist.rank()
+        n_local = int(n_games / world)
+        if n_local < 1:
+            raise ValueError("n_games=%d is fewer than the %d ranks" % (n_games, world))
+        if world > 1:
+            self.net = self.net.to(self.device)
+            azdist.broadcast_net(self.net, src=0)
+        kw = {k: self.kwargs[k] for k in ("n_playouts", "c_puct", "temperature") if k in self.kwargs}
+        s1, s2, self.last_progress = arena.play_tests(
+            self.net, self.game_name, n_local, pairing[0], pairing[1], opponent_sims=int(n_playouts_mcts), device=self.device,
+            seed=self.seed + 1000003 * self._generation + 7919 * rank, n_slots=self.n_slots, eval_backend=self.eval_backend,
+            eval_precision=self.eval_precision, **kw)
+        self._generation += 1
+        total = torch.tensor([float(s1.sum() + s2.sum()), float(2 * n_local)], dtype=torch.float64)
+        total = azdist.all_reduce_sum(total, self.device)
+        return float(total[0] / total[1])

@@ -1,7 +1,11 @@
 """`play_game_self` with the reference's interface (game_utils.py:148-206): ONE self-play game through
 the AlphaZeroBot façade (search on the GPU, one engine slot).  Bulk generation should use
 ExampleGenerator, which keeps thousands of games on the device; this entry exists for drop-in parity
-(same arguments, same example records, same numpy random stream)."""
+(same arguments, same example records, same numpy random stream).
+
+The evaluation pairings `test_zero_vs_mcts`, `test_net_vs_mcts`, `test_zero_vs_random`, `test_net_vs_random`
+(game_utils.py:53-128) keep their signatures and return shapes; each call plays its two games on the device arena
+(alphazero_openspiel_amd.arena).  `ExampleGenerator(is_test=True).generate_tests` runs n of them as one batch."""
 import numpy as np
 
 from .alphazerobot import AlphaZeroBot
@@ -51,3 +55,35 @@ def play_game_self(policy_fn, game_name, **kwargs):
             rec[3] = z
             z *= -1
     return examples
+
+
+# ---------------------------------------------------------------------- evaluation pairings (game_utils.py:53-128)
+def _one_test(policy_fn, game_name, agent, opponent, sims, kwargs):
+    from . import arena
+    s1, s2, _ = arena.play_tests(policy_fn, game_name, 1, agent, opponent, opponent_sims=sims, **kwargs)
+    return float(s1[0]), float(s2[0])
+
+
+def test_zero_vs_mcts(policy_fn, max_search_nodes, game_name, **kwargs):
+    """AlphaZeroBot (no root noise) against MCTSBot(uct_c=1, max_search_nodes, RandomRolloutEvaluator(1)), once as first
+    and once as second player -> (score1, score2, None) (game_utils.py:68-83)."""
+    return _one_test(policy_fn, game_name, "zero", "uct", max_search_nodes, kwargs) + (None,)
+
+
+def test_net_vs_mcts(policy_fn, max_search_nodes, game_name, **kwargs):
+    """NeuralNetBot against the same MCTSBot (game_utils.py:86-101)."""
+    return _one_test(policy_fn, game_name, "net", "uct", max_search_nodes, kwargs) + (None,)
+
+
+def test_zero_vs_random(policy_fn, game_name="connect_four", **kwargs):
+    """AlphaZeroBot against the uniform random bot (game_utils.py:53-65; the reference hard-codes connect_four)."""
+    return _one_test(policy_fn, game_name, "zero", "random", 0, kwargs) + (None,)
+
+
+def test_net_vs_random(policy_fn, game_name, **kwargs):
+    """NeuralNetBot against the uniform random bot -> (score1, score2) (game_utils.py:104-117)."""
+    return _one_test(policy_fn, game_name, "net", "random", 0, kwargs)
+
+
+for _f in (test_zero_vs_mcts, test_net_vs_mcts, test_zero_vs_random, test_net_vs_random):
+    _f.__test__ = False  # reference names; not pytest cases

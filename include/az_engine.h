@@ -89,7 +89,26 @@ typedef struct az_config {
     double dirichlet_alpha;
     double temperature;
     uint64_t seed;
+    /* Evaluation arena (game_utils.py:16-145, examplegenerator.py:177-195, train.py:238-270): every game is played
+     * between an AGENT driven by the network and an OPPONENT bot; game id i gives the agent the side i & 1, so the pair
+     * (2k, 2k+1) is one `test_*_vs_*` call of the reference (agent first, then agent second).  0 / 0 = self-play. */
+    int32_t arena_agent;    /* AZ_ARENA_* */
+    int32_t arena_opponent; /* AZ_OPPONENT_* */
+    int32_t opponent_sims;  /* AZ_OPPONENT_UCT: max_search_nodes of mcts.MCTSBot (game_utils.py:74-75) */
+    int32_t reserved_arena;
+    double opponent_uct_c;  /* AZ_OPPONENT_UCT: uct_c (1 in the reference's calls) */
 } az_config;
+
+#define AZ_ARENA_SELF_PLAY 0
+#define AZ_ARENA_ZERO 1 /* AlphaZeroBot outside self-play: search, then the most visited move (alphazerobot.py:86-91), tree kept
+                           across both players' moves (alphazerobot.py:60-64) */
+#define AZ_ARENA_NET 2  /* NeuralNetBot (alphazerobot.py:96-120): one evaluation, argmax of the masked, renormalised priors;
+                           configure n_playouts = 1, use_dirichlet = 0, keep_search_tree = 0 */
+#define AZ_OPPONENT_NONE 0
+#define AZ_OPPONENT_RANDOM 1 /* pyspiel.make_uniform_random_bot: a uniformly random legal action */
+#define AZ_OPPONENT_UCT 2    /* open_spiel.python.algorithms.mcts.MCTSBot(game, player, uct_c, max_search_nodes,
+                                RandomRolloutEvaluator(1)) - third party, absent from the reference tree, version unpinned:
+                                restated from its published algorithm */
 
 typedef struct az_sizes {
     int32_t num_actions;  /* A   = game.num_distinct_actions() */
@@ -185,6 +204,11 @@ int az_engine_advance(az_engine *e, const float *priors, const float *values, fl
  * initialised buffers on the first tick: slots without an outstanding request ignore them). */
 int az_engine_advance_slots(az_engine *e, int32_t first_slot, int32_t n_slots, const float *priors, const float *values,
                             float *obs_out, void *stream);
+
+/* Arena engines only: compute the opponent bot's move for every slot whose opponent is to move (one thread per slot:
+ * a uniformly random legal action, or a UCT search with random rollouts).  The next az_engine_advance applies the moves.
+ * One arena tick = az_engine_advance, az_engine_opponent_moves, PV-net forward.  Asynchronous on `stream`. */
+int az_engine_opponent_moves(az_engine *e, void *stream);
 
 /* MCTS.update_root(action) (mcts.py:192-203) for every slot, manual_moves engines only: applies
  * actions[g] (host array [G]; AZ_ACTION_NONE = leave the slot alone) to the slot's root state, keeps the chosen

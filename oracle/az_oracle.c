@@ -733,5 +733,182 @@ int orc_play_game_self(const orc_selfplay_cfg *cfg, orc_policy_fn fn, void *user
     return ply;
 }
 
+
+/* ================================================================== evaluation arena (game_utils.py:16-145)
+ * Agent (network driven) against an opponent bot.  The opponents come from OpenSpiel, which is absent from the reference
+ * tree and unpinned (see the header): `pyspiel.make_uniform_random_bot` and `open_spiel.python.algorithms.mcts.MCTSBot(game,
+ * player, uct_c, max_search_nodes, RandomRolloutEvaluator(1))` are restated from their published behaviour - "parity
+ * unpinned" for them; what IS pinned here is that the HIP arena (csrc/az_engine.hip: az_opponent_kernel, move_step) computes
+ * exactly this, given the same counter-based random stream (Philox4x32-10, Salmon et al. 2011, keyed by seed / game id /
+ * ply / purpose exactly as the device keys it). */
+typedef struct {
+    uint32_t k0, k1, c0, c1, c2, c3, out[4];
+    int have;
+} orc_philox;
+static void philox_init(orc_philox *r, uint64_t seed, uint32_t gid, uint32_t ply, uint32_t purpose, uint32_t idx) {
+    r->k0 = (uint32_t)seed;
+    r->k1 = (uint32_t)(seed >> 32);
+    r->c0 = 0;
+    r->c1 = idx;
+    r->c2 = (ply << 8) | purpose;
+    r->c3 = gid;
+    r->have = 0;
+}
+static void philox_block(orc_philox *r) {
+    uint32_t c0 = r->c0, c1 = r->c1, c2 = r->c2, c3 = r->c3, k0 = r->k0, k1 = r->k1;
+    for (int i = 0; i < 10; i++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    r->out[0] = c0; r->out[1] = c1; r->out[2] = c2; r->out[3] = c3;
+    r->c0++;
+    r->have = 2;
+}
+static double philox_u01(orc_philox *r) { /* [0,1), 53 bits; two per block, upper pair first */
+    if (!r->have) philox_block(r);
+    r->have--;
+    uint64_t x = ((uint64_t)r->out[2 * r->have] << 32) | r->out[2 * r->have + 1];
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* one uniformly random legal action */
+static int random_legal_action(const orc_state *s, orc_philox *r) {
+    int32_t legal[ORC_MAX_CELLS * 3];
+    int n = orc_legal_actions(s, legal);
+    int k = (int)(philox_u01(r) * (double)n);
+    return legal[k < n ? k : n - 1];
+}
+
+typedef struct uct_node {
+    int64_t explore_count;
+    double total_reward; /* seen by the player who moved into this node */
+    int action, n_children;
+    struct uct_node *children; /* created the first time a visited node is descended through */
+} uct_node;
+static void uct_free(uct_node *n) {
+    for (int i = 0; i < n->n_children; i++) uct_free(&n->children[i]);
+    free(n->children);
+}
+/* MCTSBot.step: max_search_nodes simulations of UCT with one random rollout per new node; most visited root child */
+static int uct_bot_action(const orc_state *root_state, int n_sims, double uct_c, orc_philox *r) {
+    uct_node root;
+    memset(&root, 0, sizeof root);
+    int root_player = root_state->nhist & 1;
+    uct_node *path[ORC_MAX_HIST + 1];
+    for (int sim = 0; sim < n_sims; sim++) {
+        orc_state s = *root_state;
+        uct_node *node = &root;
+        int depth = 0;
+        path[0] = node;
+        while (!s.terminal && node->explore_count > 0) {
+            if (!node->children) {
+                int32_t legal[ORC_MAX_CELLS * 3];
+                int n = orc_legal_actions(&s, legal);
+                node->children = (uct_node *)calloc((size_t)n, sizeof(uct_node));
+                node->n_children = n;
+                for (int k = 0; k < n; k++) node->children[k].action = legal[k];
+            }
+            double L = log((double)node->explore_count), best = -INFINITY;
+            int bi = 0;
+            for (int k = 0; k < node->n_children; k++) {
+                const uct_node *c = &node->children[k];
+                double v = c->explore_count == 0
+                               ? INFINITY
+                               : c->total_reward / (double)c->explore_count + uct_c * sqrt(L / (double)c->explore_count);
+                if (v > best) {
+                    best = v;
+                    bi = k;
+                }
+            }
+            node = &node->children[bi];
+            orc_apply_action(&s, node->action);
+            path[++depth] = node;
+        }
+        while (!s.terminal) orc_apply_action(&s, random_legal_action(&s, r)); /* RandomRolloutEvaluator(1) */
+        for (int d = 0; d <= depth; d++) {
+            int mover = (root_player + d + 1) & 1;
+            path[d]->explore_count += 1;
+            path[d]->total_reward += mover == 0 ? s.ret0 : -s.ret0;
+        }
+    }
+    int bi = 0;
+    for (int k = 1; k < root.n_children; k++)
+        if (root.children[k].explore_count > root.children[bi].explore_count) bi = k;
+    int action = root.n_children ? root.children[bi].action : -1;
+    uct_free(&root);
+    return action;
+}
+
+#define ORC_ARENA_ZERO 1
+#define ORC_ARENA_NET 2
+#define ORC_OPPONENT_RANDOM 1
+#define ORC_OPPONENT_UCT 2
+typedef struct {
+    int32_t game, rows, cols;
+    int32_t n_playouts, keep_search_tree, agent, opponent, opponent_sims;
+    double c_puct, temperature, opponent_uct_c;
+    uint64_t seed;
+    int32_t game_id; /* the agent plays side game_id & 1; the Philox stream is keyed by it */
+    int32_t reserved;
+} orc_arena_cfg;
+
+/* game_utils.play_game (game_utils.py:16-35) between the agent (AlphaZeroBot outside self-play, alphazerobot.py:42-93,
+ * or NeuralNetBot, alphazerobot.py:96-120) and the opponent bot.  actions: the moves played; returns their count,
+ * *ret0 = returns()[0]. */
+int orc_play_arena_game(const orc_arena_cfg *cfg, orc_policy_fn fn, void *user, int32_t *actions, int max_actions, double *ret0) {
+    orc_state s;
+    orc_state_init(&s, cfg->game, cfg->rows, cfg->cols);
+    int A = orc_num_actions(cfg->game, cfg->rows, cfg->cols);
+    orc_bot *bot = cfg->agent == ORC_ARENA_ZERO
+                       ? orc_bot_new(A, 0, cfg->keep_search_tree, cfg->temperature, cfg->c_puct, cfg->n_playouts, 0, 0.25, 1, fn, user)
+                       : NULL;
+    double *pol = (double *)malloc(sizeof(double) * (size_t)A), *board = (double *)malloc(sizeof(double) * 4 * ORC_MAX_CELLS);
+    int n = 0;
+    while (!s.terminal) {
+        int action;
+        if ((s.nhist & 1) == (cfg->game_id & 1)) { /* the agent's turn */
+            if (cfg->agent == ORC_ARENA_ZERO) {
+                action = orc_bot_step(bot, &s, NULL, 0.0, pol);
+            } else { /* NeuralNetBot.step */
+                double v;
+                orc_state_to_board(&s, board);
+                fn(user, &s, board, pol, &v);
+                int32_t legal[ORC_MAX_CELLS * 3];
+                int nl = orc_legal_actions(&s, legal);
+                orc_remove_illegal_actions(pol, A, legal, nl);
+                action = 0;
+                for (int a = 1; a < A; a++)
+                    if (pol[a] > pol[action]) action = a;
+            }
+        } else {
+            orc_philox r;
+            philox_init(&r, cfg->seed, (uint32_t)cfg->game_id, (uint32_t)s.nhist, 2u, 0u);
+            action = cfg->opponent == ORC_OPPONENT_RANDOM ? random_legal_action(&s, &r)
+                                                           : uct_bot_action(&s, cfg->opponent_sims, cfg->opponent_uct_c, &r);
+        }
+        if (n >= max_actions || action < 0) {
+            n = -1;
+            break;
+        }
+        actions[n++] = action;
+        orc_apply_action(&s, action);
+    }
+    *ret0 = s.ret0;
+    if (bot) orc_bot_free(bot);
+    free(pol);
+    free(board);
+    return n;
+}
+
+/* the opponent bots alone, for unit checks: the move they choose in `s` for (seed, game id) */
+int orc_opponent_action(const orc_state *s, int opponent, int n_sims, double uct_c, uint64_t seed, int32_t game_id) {
+    orc_philox r;
+    philox_init(&r, seed, (uint32_t)game_id, (uint32_t)s->nhist, 2u, 0u);
+    return opponent == ORC_OPPONENT_RANDOM ? random_legal_action(s, &r) : uct_bot_action(s, n_sims, uct_c, &r);
+}
+
 int64_t orc_nodes_alive(void) { return g_nodes_alive; }
 int64_t orc_nodes_total(void) { return g_nodes_total; }

@@ -27,6 +27,17 @@ class SelfplayCfg(C.Structure):
                 ("seed", C.c_uint64), ("max_moves", C.c_int32), ("reserved", C.c_int32)]
 
 
+class ArenaCfg(C.Structure):
+    _fields_ = [("game", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("n_playouts", C.c_int32),
+                ("keep_search_tree", C.c_int32), ("agent", C.c_int32), ("opponent", C.c_int32), ("opponent_sims", C.c_int32),
+                ("c_puct", C.c_double), ("temperature", C.c_double), ("opponent_uct_c", C.c_double), ("seed", C.c_uint64),
+                ("game_id", C.c_int32), ("reserved", C.c_int32)]
+
+
+ARENA_AGENTS = {"zero": 1, "net": 2}
+OPPONENTS = {"random": 1, "uct": 2}
+
+
 def build(force=False):
     if force or not os.path.isfile(LIB_PATH) or \
             os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(HERE, "az_oracle.c")):
@@ -69,6 +80,8 @@ def lib():
     L.orc_remove_illegal_actions.argtypes = [dp, C.c_int, ip, C.c_int]
     L.orc_play_game_self.argtypes = [C.POINTER(SelfplayCfg), POLICY_FN, vp, dp, C.c_int, dp, C.c_int,
                                      dp, dp, dp, ip, lp, C.c_int, dp, lp]
+    L.orc_play_arena_game.argtypes = [C.POINTER(ArenaCfg), POLICY_FN, vp, ip, C.c_int, dp]
+    L.orc_opponent_action.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_int32]
     L.orc_nodes_alive.restype = C.c_int64
     L.orc_nodes_total.restype = C.c_int64
     _lib = L
@@ -282,3 +295,28 @@ def play_game_self(py_policy, game_name, n_playouts=100, c_puct=2.5, temperature
             "ret0": float(ret0[0]),
             "counters": dict(zip(("sims", "evals", "terminal_hits", "sum_depth", "sum_children"),
                                  counters.tolist()))}
+
+
+def play_arena_game(py_policy, game_name, game_id, agent="zero", opponent="uct", opponent_sims=0, n_playouts=100, c_puct=2.5,
+                    temperature=1.0, keep_search_tree=True, opponent_uct_c=1.0, seed=0):
+    """game_utils.play_game between the network-driven agent (side game_id & 1) and an opponent bot, through the C
+    restatement.  Returns dict(actions, ret0)."""
+    L = lib()
+    g, r, c = parse_game(game_name)
+    A = L.orc_num_actions(g, r, c)
+    if agent == "net":
+        n_playouts, keep_search_tree = 1, False
+    cfg = ArenaCfg(g, r, c, n_playouts, int(keep_search_tree), ARENA_AGENTS[agent], OPPONENTS[opponent], int(opponent_sims),
+                   c_puct, temperature, opponent_uct_c, seed, int(game_id), 0)
+    cb = wrap_policy(py_policy, A, 4 * r * c)
+    mp = max_plies(g, r, c)
+    actions = np.zeros(mp, dtype=np.int32)
+    ret0 = np.zeros(1, dtype=np.float64)
+    n = L.orc_play_arena_game(C.byref(cfg), cb, None, _ip(actions), mp, _dp(ret0))
+    if n < 0:
+        raise RuntimeError("oracle arena game overflow")
+    return {"actions": actions[:n].tolist(), "ret0": float(ret0[0])}
+
+
+def opponent_action(state, opponent, n_sims, uct_c, seed, game_id):
+    return lib().orc_opponent_action(state.ptr, OPPONENTS[opponent], int(n_sims), float(uct_c), int(seed), int(game_id))
