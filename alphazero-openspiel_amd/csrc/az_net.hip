@@ -209,14 +209,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
         koff[ks] = zero ? 0 : (dy * p.rs + dx) * OCT_B + c8 * plane_b; // zero groups: zero weights, any finite data
         if (RP1) koff[ks] += (int)lds_base + pos_addr[0];              // the full LDS address of tile 0's fragment
     }
-    int ksp[4]; // L15: the four taps of this lane's group in the last k-step (channels 48, 49 = first 4 bytes of octet 6)
+    // L15: channels 48, 49 live in a COMPACT plane - 4 bytes per cell in the space of octet plane 6 - so that the 4-byte
+    // gather reads of the last k-step touch 16 consecutive dwords per 16 columns (at the octet planes' 16-byte cell stride
+    // they were 4-way bank conflicted: 17 % of the kernel's LDS cycles, profiles/r2_bench_default_pmc_summary.txt)
+    int p6_addr[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) p6_addr[nt] = region + 6 * plane_b + ((pos_addr[nt] - region) >> 2);
+    int ksp[4]; // the four taps of this lane's group in the last k-step
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int tap = 4 * q + i;
         tap = tap > 8 ? 8 : tap; // (taps past the ninth carry zero weights)
         int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        ksp[i] = (dy * p.rs + dx) * OCT_B + 6 * plane_b;
-        if (RP1) ksp[i] += (int)lds_base + pos_addr[0];
+        ksp[i] = (dy * p.rs + dx) * 4;
+        if (RP1) ksp[i] += (int)lds_base + p6_addr[0];
     }
     // conv 0 reads the 4 input planes only (octet 0): K = 9 taps x 1 octet, packed as ONE 4-k-step chunk
     // (group g < 9 = tap g of octet 0, groups 9..15 zero weights) instead of 16 k-steps that are 6/7 zeros.
@@ -344,8 +350,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             // dword i (tap 4q + i, channels 48, 49) of the gather k-step's B fragment for column tile nt
             auto read_bsp = [&](unsigned &dst, auto i_c, auto nt_c) {
                 constexpr int i = decltype(i_c)::value, nt = decltype(nt_c)::value;
-                if constexpr (RP1) READ_B32_OFF(dst, (unsigned)ksp[i], nt * 256);
-                else READ_B32_OFF(dst, lds_base + pos_addr[nt] + opaque(ksp[i]), 0);
+                if constexpr (RP1) READ_B32_OFF(dst, (unsigned)ksp[i], nt * 64);
+                else READ_B32_OFF(dst, lds_base + p6_addr[nt] + opaque(ksp[i]), 0);
             };
             // Read order inside a k-step: A0..A3, B0, B1, ... (read index: A_mt = mt, B_nt = 4 + nt; gather k-step: the four
             // dwords of B_nt are reads 4 + 4 nt .. 7 + 4 nt).  LDS returns in order, so before the MFMAs of column tile nt it
@@ -459,8 +465,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                         }
                         o = lrelu_h4(__builtin_convertvector(__builtin_elementwise_fma(sc, xv, sh), half4)); // one v_pk_fma_f32 per pair
                     }
-                    const int wa = (wr && grow[nt] >= 0) ? pos_addr[nt] + woff : trash;
-                    *(half4 *)(lds + wa) = o;
+                    if (L15 && mt == 3) { // channels 48, 49 (lanes q = 0) -> the compact plane; 50..63 do not exist
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        const int wa = (q == 0 && grow[nt] >= 0) ? p6_addr[nt] : trash;
+                        *(unsigned *)(lds + wa) = __builtin_bit_cast(u32x2, o)[0];
+                    } else {
+                        const int wa = (wr && grow[nt] >= 0) ? pos_addr[nt] + woff : trash;
+                        *(half4 *)(lds + wa) = o;
+                    }
                 }
             }
         };
@@ -553,14 +565,17 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3_kernel(TowerParams p) {
         koff[ks] = zero ? 0 : (dy * p.rs + dx) * OCT_B + c8 * plane_b;
         if (RP1) koff[ks] += (int)lds_base + pos_addr[0];
     }
+    int p6_addr[NT]; // compact plane of channels 48, 49 (4 bytes per cell, see az_tower_kernel); its lo twin at + lo_off
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) p6_addr[nt] = region + 6 * plane_b + ((pos_addr[nt] - region) >> 2);
     int ksp[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int tap = 4 * q + i;
         tap = tap > 8 ? 8 : tap;
         int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        ksp[i] = (dy * p.rs + dx) * OCT_B + 6 * plane_b;
-        if (RP1) ksp[i] += (int)lds_base + pos_addr[0];
+        ksp[i] = (dy * p.rs + dx) * 4;
+        if (RP1) ksp[i] += (int)lds_base + p6_addr[0];
     }
     int koff0[AZ_NET_K0STEPS];
 #pragma unroll
@@ -686,11 +701,11 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3_kernel(TowerParams p) {
                 constexpr bool lo = r >= 4 * NT;
                 constexpr int nt = (r % (4 * NT)) / 4, i = r % 4;
                 if constexpr (RP1) {
-                    if constexpr (lo) READ_B32_OFF(spl[nt][i], (unsigned)ksp[i], nt * 256 + X3_LOFF_RP1);
-                    else READ_B32_OFF(sph[nt][i], (unsigned)ksp[i], nt * 256);
+                    if constexpr (lo) READ_B32_OFF(spl[nt][i], (unsigned)ksp[i], nt * 64 + X3_LOFF_RP1);
+                    else READ_B32_OFF(sph[nt][i], (unsigned)ksp[i], nt * 64);
                 } else {
-                    if constexpr (lo) READ_B32_OFF(spl[nt][i], lds_base + pos_addr[nt] + lo_off + opaque(ksp[i]), 0);
-                    else READ_B32_OFF(sph[nt][i], lds_base + pos_addr[nt] + opaque(ksp[i]), 0);
+                    if constexpr (lo) READ_B32_OFF(spl[nt][i], lds_base + p6_addr[nt] + lo_off + opaque(ksp[i]), 0);
+                    else READ_B32_OFF(sph[nt][i], lds_base + p6_addr[nt] + opaque(ksp[i]), 0);
                 }
             };
             static_for<8>([&](auto r_c) { read_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, r_c); });
@@ -798,9 +813,16 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3_kernel(TowerParams p) {
                     }
                     half4 hi, lo;
                     split4(o, hi, lo);
-                    const bool live = wr && grow[nt] >= 0;
-                    *(half4 *)(lds + (live ? pos_addr[nt] + woff : trash)) = hi;
-                    *(half4 *)(lds + (live ? pos_addr[nt] + woff + lo_off : trash + 8)) = lo;
+                    if (L15 && mt == 3) { // channels 48, 49 -> the compact planes
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        const bool live = q == 0 && grow[nt] >= 0;
+                        *(unsigned *)(lds + (live ? p6_addr[nt] : trash)) = __builtin_bit_cast(u32x2, hi)[0];
+                        *(unsigned *)(lds + (live ? p6_addr[nt] + lo_off : trash + 8)) = __builtin_bit_cast(u32x2, lo)[0];
+                    } else {
+                        const bool live = wr && grow[nt] >= 0;
+                        *(half4 *)(lds + (live ? pos_addr[nt] + woff : trash)) = hi;
+                        *(half4 *)(lds + (live ? pos_addr[nt] + woff + lo_off : trash + 8)) = lo;
+                    }
                 }
             }
         };
@@ -1071,6 +1093,7 @@ static TowerGeom tower_geom(int bpw, int waves, int H, int W) {
     int act = g.waves * wave_act;
     // 32 KiB weight chunks (half the barriers) when LDS allows; not with 8 waves: the longer unrolled body spills there
     g.ck = (act + 6144 + 2 * 8 * 4096 <= 160 * 1024) ? 8 : 4; // 32 KiB chunks (half the barriers) when LDS allows
+
     g.off_epi = 2 * g.ck * 4096;
     g.off_act = g.off_epi + 2048 + 8 * 64 * 8; // epilogue ring (2 KiB) + trash slots (8 B per thread, up to 512 threads)
     g.lds = g.off_act + act;
