@@ -184,12 +184,15 @@ def main():
     if world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "off":
         # host-core baseline first: child processes, before this process initialises the GPU
         cpu = cpu_baseline(args.game, args.playouts, args.blocks, args.filters, args.seed, quick=args.cpu_baseline == "quick")
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(args.backend)
     local_rank = local_rank % max(1, torch.cuda.device_count())  # rehearsal: several ranks may share one GPU (gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL communicator bound to this rank's GPU
+        else:
+            dist.init_process_group(args.backend)
 
     from alphazero_openspiel_amd import distributed as azdist
     from alphazero_openspiel_amd import engine as E
@@ -223,7 +226,9 @@ def main():
 
     # game capacity: warm-up + timed steps + the instrumented pass + the reference-precision legs (bounded by wall time;
     # at most ~1500 games/s) - a slot that finds no game left goes idle, which would understate those legs
-    n_total = (Wm + K + 2) * G + int(1500 * 1.5 * max(0.0, args.ref_seconds)) + G
+    n_total = (Wm + K + 2) * G
+    if world == 1:
+        n_total += int(1500 * 1.5 * max(0.0, args.ref_seconds)) + G
     eng = E.SelfPlayEngine(game, G, n_playouts=S, max_games=n_total, device=device, seed=args.seed + 7919 * rank,
                            nodes_per_slot=args.nodes_per_slot, max_sims_per_tick=args.max_sims_per_tick,
                            chain_window_us=args.chain_window_us)
@@ -257,7 +262,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     def run_until(n_done):
         ticks = 0
@@ -334,14 +342,14 @@ def main():
     peak = MFMA_PEAK_TFLOPS[args.dtype]
 
     # HBM bytes per launch measured with rocprofv3 PMC counters on this exact command (separate FETCH_SIZE and
-    # WRITE_SIZE passes, profiles/r1_hbm_traffic_pmc.txt).  They cannot be collected from inside this process, so
+    # WRITE_SIZE passes, tools/profile_round.sh -> profiles/r2_bench_default_pmc_summary.txt; KB per launch).  They cannot be collected from inside this process, so
     # they are quoted only when the workload is the profiled one.  Net: FETCH_SIZE doubled (wide 16-B/lane streams
     # are reported at half size on gfx950, MI355X_MICROARCH.md); tree: uncorrected (narrow accesses, uncalibrated).
     traffic_net = traffic_tree = None
     if (game.name, G, S, args.blocks, args.filters, args.net, args.weights) == ("connect_four", 4096, 400, 10, 50,
                                                                                 "fused", "random"):
-        traffic_net = 2 * (5257.5e3 + 11125.5e3) + 21547.2e3 + 128.0e3
-        traffic_tree = 4877.7e3 + 5802.6e3
+        traffic_net = 2 * (5263e3 + 11130e3) + 21570e3 + 128e3
+        traffic_tree = 4878e3 + 5803e3
 
     # ---- reference-precision legs: the SAME engine, slots, games in flight and net weights, evaluated at the reference's
     # precision (Net.forward is fp32, network.py:48-64) for a bounded wall time each.  Games finished in the window count.
@@ -430,7 +438,7 @@ def main():
                                    + ", %d boards/launch" % G,
                          "achieved": net_tflops, "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
                          "frac_end_to_end": e2e_tflops / peak, "end_to_end_tflops": e2e_tflops,
-                         "traffic": traffic_net, "traffic_unit": "bytes/launch (PMC, profiles/r1_hbm_traffic_pmc.txt)",
+                         "traffic": traffic_net, "traffic_unit": "bytes/launch (PMC, profiles/r2_bench_default_pmc_summary.txt)",
                          "flops_per_eval": f_eval, "ms_per_launch": 1e3 * t_net,
                          "batch_fill": evals_tick / G},
             "roofline_tree": {"bound": "hbm", "kernel": "az_advance_kernel (playouts + move step)",
