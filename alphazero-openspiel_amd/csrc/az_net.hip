@@ -35,6 +35,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // structure so its cost can be read off the clock.  Outputs are wrong by construction; never shipped.
 //   AZ_ABL_NOEPI   no epilogue arithmetic / LDS writes        AZ_ABL_NOB    no B-fragment (activation) LDS reads
 //   AZ_ABL_NOA     no A-fragment (weight) LDS reads           AZ_ABL_NODMA  no weight DMA and no chunk barrier
+//   AZ_ABL_NOBARRIER  chunk barriers dropped (the DMA stays)   AZ_ABL_SKEW=n waves 4..7 start n x 64 cycles late
+//   (round 2: NOBARRIER alone and with SKEW = 30 / 60 - the two waves of a SIMD running a third / half a conv apart -
+//    all time within noise of the shipped kernel: de-phasing the wave pairs buys nothing)
 #define OCT_B 16 // one cell of one channel-octet plane: 8 fp16
 #define AZ_NET_K0STEPS 4 // k-steps of conv 0 on the device (9 taps x the one octet holding the input planes, padded to 16 groups)
 #define N_OCT 7  // 56 channels
@@ -236,6 +239,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
     }
 
     f32x4 acc[4][NT], xres[4][NT];
+#ifdef AZ_ABL_SKEW // (timing-only) waves 4..7 start AZ_ABL_SKEW x 64 cycles late
+    if (wave >= 4)
+        for (int i = 0; i < AZ_ABL_SKEW; i++) __builtin_amdgcn_s_sleep(1);
+#endif
     // ---- prologue: a = lrelu(bn1(x0)) -> octet 0; block-1 skip conv3(x0) in fp32 -> residual stream --------
     {
         f32x4 sw[4][4]; // skip weights of this lane's 16 output channels: [mt][r] -> 4 input planes
@@ -324,7 +331,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             // buffer is free for the next chunk's DMA.
 #ifndef AZ_ABL_NODMA
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef AZ_ABL_NOBARRIER // (timing-only experiment: how much would de-phasing the two waves of a SIMD be worth?)
             __syncthreads();
+#endif
             if (chunk + 1 < n_chunks) issue_chunk(chunk + 1);
             if (!IS_FIRST && part == 0 && wave == 0) // this conv's epilogue parameters ride the same DMA path into a 2-slot ring;
                                                      // they land before the next chunk barrier, long before the epilogue reads them
