@@ -76,14 +76,14 @@ def cpu_model():
     return "unknown"
 
 
-def _cpu_leg(n_workers, games_each, game_name, S, n_blocks, n_filters, weight_seed, budget_s):
+def _cpu_leg(n_workers, games_each, game_name, S, n_blocks, n_filters, weight_seed, budget_s, checkpoint=None):
     """n_workers fresh child processes (python -m oracle.cpu_selfplay), each playing FULL self-play games with the C oracle
     + a batch-1 torch-CPU net on one thread; they start together after a READY/GO handshake.  -> aggregate dict."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONDONTWRITEBYTECODE="1")
     cmd = [sys.executable, "-m", "oracle.cpu_selfplay", "--game", game_name, "--games", str(games_each), "--playouts", str(S),
            "--blocks", str(n_blocks), "--filters", str(n_filters), "--weight-seed", str(weight_seed), "--handshake",
-           "--budget-s", str(budget_s)]
+           "--budget-s", str(budget_s)] + (["--checkpoint", checkpoint] if checkpoint else [])
     procs = [subprocess.Popen(cmd + ["--seed", str(100 + i)], cwd=ROOT, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE,
                               text=True) for i in range(n_workers)]
     try:
@@ -111,7 +111,7 @@ def _cpu_leg(n_workers, games_each, game_name, S, n_blocks, n_filters, weight_se
             "seconds": wall, "workers": n_workers, "ms_per_eval_per_core": 1e3 * sum(r["seconds"] for r in res) / max(1, evals)}
 
 
-def cpu_baseline(game_name, S, n_blocks, n_filters, weight_seed, quick=False):
+def cpu_baseline(game_name, S, n_blocks, n_filters, weight_seed, quick=False, checkpoint=None):
     """the CPU restatement (oracle/az_oracle.c: same algorithm, strictly sequential playouts per tree, tree
     reuse, root Dirichlet, one batch-1 Net.forward per leaf through torch on the CPU - what a reference worker process does)
     on this box's host cores, FULL games: all cores (>= 64 games), one thread (8 games), and the C1 plumbing point
@@ -120,8 +120,10 @@ def cpu_baseline(game_name, S, n_blocks, n_filters, weight_seed, quick=False):
     cores = host_cores()
     workers = max(1, min(cores, 64))
     games_each = 1 if quick else max(1, -(-64 // workers))
-    many = _cpu_leg(workers, games_each, game_name, S, n_blocks, n_filters, weight_seed, budget_s=(10 if quick else 45))
-    one = _cpu_leg(1, 1 if quick else 8, game_name, S, n_blocks, n_filters, weight_seed, budget_s=(5 if quick else 50))
+    many = _cpu_leg(workers, games_each, game_name, S, n_blocks, n_filters, weight_seed, budget_s=(10 if quick else 45),
+                    checkpoint=checkpoint)
+    one = _cpu_leg(1, 1 if quick else 8, game_name, S, n_blocks, n_filters, weight_seed, budget_s=(5 if quick else 50),
+                   checkpoint=checkpoint)
     c1 = _cpu_leg(1, 2 if quick else 8, "connect_four", 25, 2, 50, weight_seed, budget_s=10)
     return {
         "value": many["games_per_s"], "unit": "games/s", "cores": workers, "kind": "port",
@@ -183,7 +185,12 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "off":
         # host-core baseline first: child processes, before this process initialises the GPU
-        cpu = cpu_baseline(args.game, args.playouts, args.blocks, args.filters, args.seed, quick=args.cpu_baseline == "quick")
+        ckpt = None
+        if args.weights == "checkpoint":
+            tag = {"connect_four": "connect_four", "breakthrough(rows=6,columns=6)": "breakthrough6"}.get(args.game)
+            ckpt = os.path.join(ROOT, "tests", "golden", "checkpoint_%s.npz" % tag) if tag else None
+        cpu = cpu_baseline(args.game, args.playouts, args.blocks, args.filters, args.seed, quick=args.cpu_baseline == "quick",
+                           checkpoint=ckpt)
     local_rank = local_rank % max(1, torch.cuda.device_count())  # rehearsal: several ranks may share one GPU (gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)

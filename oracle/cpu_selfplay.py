@@ -16,7 +16,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def play(game_name, n_games, S, n_blocks, n_filters, seed, handshake=False, budget_s=None, weight_seed=1):
+def play(game_name, n_games, S, n_blocks, n_filters, seed, handshake=False, budget_s=None, weight_seed=1, checkpoint=None):
     import numpy as np
     import torch
 
@@ -28,7 +28,11 @@ def play(game_name, n_games, S, n_blocks, n_filters, seed, handshake=False, budg
     g = Game(game_name)
     A = g.num_distinct_actions()
     torch.manual_seed(weight_seed)  # same weights in every worker, and as bench.py's GPU net (torch.manual_seed(args.seed))
-    net = Net(g.information_state_normalized_vector_shape(), A, n_blocks=n_blocks, n_filters=n_filters).eval()
+    if checkpoint:  # the reference's shipped weights (tests/golden/checkpoint_*.npz): realistic game lengths and tree shapes
+        from alphazero_openspiel_amd.network import load_npz_checkpoint
+        net = load_npz_checkpoint(checkpoint, g.information_state_normalized_vector_shape(), A).eval()
+    else:
+        net = Net(g.information_state_normalized_vector_shape(), A, n_blocks=n_blocks, n_filters=n_filters).eval()
 
     def policy(board):
         with torch.no_grad():
@@ -65,9 +69,10 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--weight-seed", type=int, default=1)
     ap.add_argument("--budget-s", type=float, default=None, help="stop starting new games after this many seconds")
+    ap.add_argument("--checkpoint", default=None, help="npz checkpoint to load instead of random-initialised weights")
     ap.add_argument("--handshake", action="store_true", help="print READY, then wait for a line on stdin before playing")
     a = ap.parse_args()
-    print(json.dumps(play(a.game, a.games, a.playouts, a.blocks, a.filters, a.seed, a.handshake, a.budget_s, a.weight_seed)))
+    print(json.dumps(play(a.game, a.games, a.playouts, a.blocks, a.filters, a.seed, a.handshake, a.budget_s, a.weight_seed, a.checkpoint)))
 
 
 if __name__ == "__main__":

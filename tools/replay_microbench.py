@@ -51,7 +51,5 @@ t_g = time.perf_counter() - t
 print("graphed: %d x (gather 256 + net_step): %.2f s (%.2f ms/step), last losses %.4f %.4f" % (a.batches, t_g, 1e3 * t_g / a.batches, float(gs.loss_p), float(gs.loss_v)))
 # host path for comparison: export -> python lists -> restated remove_duplicates (what train.py does)
 t = time.perf_counter(); ex = eng.export(); host = E.examples_from_export(g, ex); t_list = time.perf_counter() - t
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import pyreplay  # noqa: E402  (timing comparison only)
-t = time.perf_counter(); u = pyreplay.remove_duplicates([s for gm in host for s in gm]); t_hd = time.perf_counter() - t
-print("host path: export+lists %.2f s, python remove_duplicates %.2f s -> %d unique" % (t_list, t_hd, len(u)))
+print("host path for comparison: export + reference-format python lists %.2f s (the reference's remove_duplicates then walks them in "
+      "Python; the CPU restatement of it is test infrastructure - tests/test_replay.py times nothing)" % t_list)
