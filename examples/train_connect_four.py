@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The reference's Trainer.run loop (train.py:272-293) with every stage on the GPU:
 
-    generation:  self-play (HIP search + fused fp16 net)  ->  device replay store (FIFO, remove_duplicates)
+    generation:  self-play (HIP search + fused net)  ->  device replay store (FIFO, remove_duplicates)
                  ->  n_batches x (gather 256 + net_step, replayed as one HIP graph)
+                 ->  every --eval-every generations: Trainer.test_agent (train.py:238-270) on the device arena
 
     python examples/train_connect_four.py --generations 3 --games 512 --playouts 100
 
@@ -18,7 +19,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from alphazero_openspiel_amd import engine as E, games, replay  # noqa: E402
+from alphazero_openspiel_amd import arena, engine as E, games, replay  # noqa: E402
 from alphazero_openspiel_amd.fusednet import FusedNet  # noqa: E402
 from alphazero_openspiel_amd.network import Net  # noqa: E402
 
@@ -33,6 +34,9 @@ def main():
     ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--backup", default="on-policy", choices=["on-policy", "soft-Z", "A0C", "off-policy"])
     ap.add_argument("--save", default=None, help="directory for <generation>.pth checkpoints")
+    ap.add_argument("--precision", default="f32x", choices=["f32x", "f16"], help="fused-net arithmetic (f32x = fp32-grade)")
+    ap.add_argument("--eval-every", type=int, default=0, help="run test_agent every N generations (0 = never)")
+    ap.add_argument("--tests", type=int, default=200, help="n_tests (train.py:30)")
     a = ap.parse_args()
 
     dev = torch.device("cuda:0")
@@ -47,7 +51,7 @@ def main():
         net.eval()
         eng = E.SelfPlayEngine(game, min(a.games, 4096), n_playouts=a.playouts, backup=a.backup, max_games=a.games,
                                device=dev, seed=gen)
-        prog = E.run_selfplay(eng, FusedNet(net, dev, max_boards=eng.G), a.games, use_graph=True)
+        prog = E.run_selfplay(eng, FusedNet(net, dev, max_boards=eng.G, precision=a.precision), a.games, use_graph=True)
         t_play = time.perf_counter() - t0
         if gen % 2 == 0 and n_buffer < n_buffer_max:                       # Trainer.update_buffer_size
             n_buffer += a.games
@@ -72,6 +76,15 @@ def main():
               "%d batches in %.2f s, loss_p %.4f loss_v %.4f" %
               (gen, a.games, prog["moves"] / a.games, prog["sims"] / 1e6, t_play, st["n_games"], st["n_examples"], n_unique,
                a.batches, t_train, lp, lv), flush=True)
+        if a.eval_every and gen % a.eval_every == 0:                        # Trainer.test_agent (train.py:238-270)
+            net.eval()
+            t2 = time.perf_counter()
+            out = []
+            for agent, opp, sims in (("net", "random", 0), ("net", "uct", 100), ("zero", "uct", 200), ("net", "uct", 200)):
+                s1, s2, _ = arena.play_tests(net, a.game, a.tests, agent, opp, opponent_sims=sims, device=dev, seed=gen,
+                                             eval_precision=a.precision, c_puct=2.5)
+                out.append("%s vs %s%s: %+.3f" % (agent, opp, sims or "", float((s1.sum() + s2.sum()) / (2 * a.tests))))
+            print("        test_agent (%d tests each, %.2f s): %s" % (a.tests, time.perf_counter() - t2, " | ".join(out)), flush=True)
         if a.save:
             os.makedirs(a.save, exist_ok=True)
             torch.save(net.state_dict(), os.path.join(a.save, "%d.pth" % gen))
