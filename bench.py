@@ -169,6 +169,9 @@ def main():
                     help="slot groups ticking on their own HIP streams (BASELINE configs[4]: overlapped PV-eval / tree-search "
                          "streams): a group's tree search and launch gaps run beside another group's forward")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--ticks-per-graph", type=int, default=8,
+                    help="ticks captured per HIP graph (one replay = that many ticks: fewer graph-boundary bubbles; measured 1 -> 4 -> 16: "
+                         "2814 -> 2873 -> 2889 games/s on one box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "quick", "off"],
                     help="full = SURVEY 8(d): all cores >= 64 full games + 1 thread 8 games + C1 point (~1.5 min); quick = 1 game per leg")
@@ -257,8 +260,12 @@ def main():
         torch.cuda.synchronize(device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            tick_eager()
+            for _ in range(max(1, args.ticks_per_graph)):
+                tick_eager()
     tick = graph.replay if graph is not None else tick_eager
+    tpg = max(1, args.ticks_per_graph) if graph is not None else 1
+    if args.check_every % tpg:
+        raise SystemExit("--check-every must be a multiple of --ticks-per-graph")
     sync_groups = lambda: None
     if args.overlap > 1:  # k slot groups, each [advance_slots, forward] on its own stream / graph
         if args.net != "fused":
@@ -277,7 +284,7 @@ def main():
     def run_until(n_done):
         ticks = 0
         while True:
-            for _ in range(args.check_every):
+            for _ in range(args.check_every // tpg):
                 tick()
             ticks += args.check_every
             sync_groups()
@@ -434,7 +441,7 @@ def main():
                                          "its default is the fp32-grade 'f32x' mode timed in reference_precision)") if args.net == "fused" else args.dtype,
                        "tree_dtype": "f64", "c_puct": 2.5, "temperature": 1.0, "dirichlet_alpha": 0.3,
                        "parallelism": "games sharded over %d GPU(s), no collective inside the search" % world,
-                       "hip_graph": graph is not None},
+                       "hip_graph": graph is not None, "ticks_per_graph": tpg},
             "sims_per_s": sims_all / dt_all, "evals_per_s": evals_all / dt_all,
             "games_timed": games_all, "ticks_timed_rank0": ticks,
             "mean_plies_per_game": plies_per_game, "mean_select_depth": d_mean, "mean_children_scanned": a_sel,
