@@ -294,10 +294,30 @@ __device__ uint32_t compact_subtree(const Pool &a, const Pool &b, uint32_t root,
             int o = __shfl_xor(mx, off);
             mx = o > mx ? o : mx;
         }
-        for (int k = 0; k < mx; k++)
-            if (k < nch) {
-                uint32_t si = oc0 + k, di = dst + k;
-                b.nd[di] = a.nd[si];
+        // (the two pool halves never overlap: batch the loads of four children before their stores, so that four HBM round
+        //  trips overlap instead of one load -> store -> load chain per child)
+        for (int k0 = 0; k0 < mx; k0 += 4)
+            if (k0 < nch) { // a node = two 16-byte words; clamped, unconditional loads keep the four nodes in registers
+                const int last = nch - 1;
+                const uint4 *s0 = (const uint4 *)(a.nd + oc0 + k0), *s1 = (const uint4 *)(a.nd + oc0 + (k0 + 1 < last ? k0 + 1 : last)),
+                            *s2 = (const uint4 *)(a.nd + oc0 + (k0 + 2 < last ? k0 + 2 : last)),
+                            *s3 = (const uint4 *)(a.nd + oc0 + (k0 + 3 < last ? k0 + 3 : last));
+                const uint4 a0 = s0[0], b0 = s0[1], a1 = s1[0], b1 = s1[1], a2 = s2[0], b2 = s2[1], a3 = s3[0], b3 = s3[1];
+                uint4 *d = (uint4 *)(b.nd + dst + k0);
+                d[0] = a0;
+                d[1] = b0;
+                if (k0 + 1 < nch) {
+                    d[2] = a1;
+                    d[3] = b1;
+                }
+                if (k0 + 2 < nch) {
+                    d[4] = a2;
+                    d[5] = b2;
+                }
+                if (k0 + 3 < nch) {
+                    d[6] = a3;
+                    d[7] = b3;
+                }
             }
         __threadfence_block(); // the next chunk reads what this one wrote (same wave, global memory)
         f += (uint32_t)total;
