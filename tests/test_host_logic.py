@@ -255,3 +255,57 @@ def test_example_gather_and_weight_broadcast_world_size_2(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()  # (stdout of the ranks interleaves)
+
+
+# ------------------------------------------------------------------------------------- round-2 host helpers
+def test_slot_groups_cover_the_slots_in_multiples_of_eight():
+    from alphazero_openspiel_amd.engine import slot_groups
+    for G, k in ((4096, 2), (4096, 3), (100, 3), (16, 2), (5, 2), (2048, 4), (7, 1)):
+        groups = slot_groups(G, k)
+        assert groups[0][0] == 0 and sum(n for _, n in groups) == G and len(groups) <= k
+        assert all(f == sum(n for _, n in groups[:i]) for i, (f, _) in enumerate(groups))   # contiguous
+        assert all(n % 8 == 0 for _, n in groups[:-1])                                      # whole tower workgroups
+
+
+def test_device_export_layout_round_trip():
+    """The packed layout of az_engine_export_device (include/az_engine.h) as the host sees it: 16-byte aligned arrays in the
+    order of az_example_view; unpack gives back what was packed."""
+    from alphazero_openspiel_amd.engine import device_export_layout, unpack_device_export
+    n, mp, mc = 5, 42, 7
+    layout, total = device_export_layout(n, mp, mc)
+    assert [name for name, _, _, _ in layout] == ["game_len", "game_ret0", "states", "move", "n_children", "child_action",
+                                                  "child_visits", "value"]
+    assert all(off % 16 == 0 for _, _, _, off in layout) and total % 16 == 0
+    rng = np.random.RandomState(0)
+    buf = np.zeros(total, dtype=np.uint8)
+    want = {}
+    for name, dt, shape, off in layout:
+        a = (rng.randint(0, 200, size=shape)).astype(dt)
+        want[name] = a
+        raw = a.reshape(-1).view(np.uint8)
+        buf[off:off + raw.size] = raw
+    got = unpack_device_export(buf, n, mp, mc, start_ply=3)
+    assert got["start_ply"] == 3 and all((got[k] == want[k]).all() for k in want)
+    with pytest.raises(ValueError):
+        unpack_device_export(buf[:-16], n, mp, mc)
+
+
+def test_arena_pair_scores_follow_the_reference_convention():
+    """game ids (2k, 2k+1) = one test_*_vs_* call: score1 = the first player's return with the agent first, score2 = MINUS the
+    first player's return with the agent second (game_utils.py:76-82); generate_tests averages sum(score1 + score2) / (2 n)."""
+    from alphazero_openspiel_amd.arena import pair_scores
+    s1, s2 = pair_scores([1.0, -1.0, -1.0, -1.0, 0.0, 1.0])
+    assert s1.tolist() == [1.0, -1.0, 0.0] and s2.tolist() == [1.0, 1.0, -1.0]
+    assert float((s1.sum() + s2.sum()) / (2 * 3)) == pytest.approx(1.0 / 6)
+
+
+def test_bench_host_core_detection_respects_the_cgroup_quota(tmp_path, monkeypatch):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = bench.host_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert isinstance(bench.cpu_model(), str) and bench.cpu_model()
+    assert bench.net_flops_per_eval(6, 7, 7, 10) == 36111600      # SURVEY 8(d): 36.1 MFLOP for the 10-block connect_four net
+    assert abs(bench.tree_bytes_per_sim(6.5, 7, 7, 7, 6, 7) - 1722) < 1   # ... and its ~1.7 kB per sim
