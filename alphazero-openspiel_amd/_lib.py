@@ -13,7 +13,7 @@ RNG_PHILOX, RNG_INJECTED = 0, 1
 FAULTS = {1: "POOL_EXHAUSTED", 2: "PLY_OVERFLOW", 4: "NO_VISITS", 8: "BAD_PRIOR", 16: "ILLEGAL_ACTION"}
 ACTION_NONE, ACTION_SEARCH_AGAIN = -1, -2
 ARENA_AGENTS = {None: 0, "zero": 1, "net": 2}
-OPPONENTS = {None: 0, "random": 1, "uct": 2}
+OPPONENTS = {None: 0, "random": 1, "uct": 2, "external": 3}
 
 
 class AzConfig(C.Structure):
@@ -25,7 +25,7 @@ class AzConfig(C.Structure):
                 ("c_puct", C.c_double), ("dirichlet_ratio", C.c_double), ("dirichlet_alpha", C.c_double),
                 ("temperature", C.c_double), ("seed", C.c_uint64),
                 ("arena_agent", C.c_int32), ("arena_opponent", C.c_int32), ("opponent_sims", C.c_int32),
-                ("reserved_arena", C.c_int32), ("opponent_uct_c", C.c_double)]
+                ("arena_flip", C.c_int32), ("opponent_uct_c", C.c_double)]
 
 
 class AzSizes(C.Structure):
@@ -90,6 +90,7 @@ PROTOTYPES = [
     ("az_engine_advance", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("az_engine_advance_slots", C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     ("az_engine_opponent_moves", C.c_int, [_vp, _vp]),
+    ("az_engine_exchange_moves", C.c_int, [_vp, _vp, _vp]),
     ("az_engine_update_root", C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32, _vp]),
     ("az_engine_progress", C.c_int, [_vp, C.POINTER(AzProgress), _vp]),
     ("az_engine_poll", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_uint32), _vp]),

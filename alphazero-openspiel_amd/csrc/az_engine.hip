@@ -427,7 +427,7 @@ __device__ __forceinline__ bool finish_game_take_next(const Params &p, int g, in
 }
 // arena: the agent plays side gid & 1; is it the OPPONENT's turn in state s of game gid?
 __device__ __forceinline__ bool opponent_to_move(const Params &p, int gid, const AzState &s) {
-    return p.arena_agent != AZ_ARENA_SELF_PLAY && ((s.ply ^ gid) & 1);
+    return p.arena_agent != AZ_ARENA_SELF_PLAY && ((s.ply ^ gid ^ p.arena_flip) & 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -950,7 +950,7 @@ template <int GAME> __device__ int uct_search(const Params &p, int g, const AzSt
 
 template <int GAME> __global__ __launch_bounds__(64) void az_opponent_kernel(Params p) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= p.G || p.phase[g] != PH_OPPONENT) return;
+    if (g >= p.G || p.phase[g] != PH_OPPONENT || p.opp_kind == AZ_OPPONENT_EXTERNAL) return;
     AzState s;
     s.bb0 = p.bb0[g];
     s.bb1 = p.bb1[g];
@@ -1031,7 +1031,7 @@ __global__ void az_reset_kernel(Params p) {
     if (g >= p.G) return;
     bool active = (long long)g < p.n_games;
     p.phase[g] = !active ? PH_IDLE
-                 : ((p.arena_agent != AZ_ARENA_SELF_PLAY && ((p.start.ply ^ g) & 1)) ? PH_OPPONENT
+                 : ((p.arena_agent != AZ_ARENA_SELF_PLAY && ((p.start.ply ^ g ^ p.arena_flip) & 1)) ? PH_OPPONENT
                                                                                        : (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN));
     p.gid[g] = active ? g : -1;
     p.bb0[g] = p.start.bb0;
@@ -1137,11 +1137,12 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
         return AZ_E_INVALID;
     }
     if (c.arena_agent < AZ_ARENA_SELF_PLAY || c.arena_agent > AZ_ARENA_NET ||
-        (c.arena_agent != AZ_ARENA_SELF_PLAY && (c.arena_opponent != AZ_OPPONENT_RANDOM && c.arena_opponent != AZ_OPPONENT_UCT)) ||
+        (c.arena_agent != AZ_ARENA_SELF_PLAY && (c.arena_opponent < AZ_OPPONENT_RANDOM || c.arena_opponent > AZ_OPPONENT_EXTERNAL)) ||
+        (c.arena_flip != 0 && c.arena_flip != 1) || (c.arena_agent == AZ_ARENA_SELF_PLAY && c.arena_flip) ||
         (c.arena_agent == AZ_ARENA_SELF_PLAY && c.arena_opponent != AZ_OPPONENT_NONE) ||
         (c.arena_opponent == AZ_OPPONENT_UCT && (c.opponent_sims < 2 || c.opponent_sims > 100000 || !(c.opponent_uct_c >= 0.0))) ||
         (c.arena_agent != AZ_ARENA_SELF_PLAY && (c.manual_moves || c.rng_mode != AZ_RNG_PHILOX))) {
-        g_create_err = "bad arena configuration (agent 0..2; an arena needs opponent RANDOM or UCT with 2 <= opponent_sims, "
+        g_create_err = "bad arena configuration (agent 0..2; an arena needs opponent RANDOM, UCT with 2 <= opponent_sims, or EXTERNAL; "
                        "rng_mode PHILOX, manual_moves 0)";
         return AZ_E_INVALID;
     }
@@ -1193,6 +1194,7 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     p.arena_agent = c.arena_agent;
     p.opp_kind = c.arena_opponent;
     p.opp_sims = c.opponent_sims;
+    p.arena_flip = c.arena_flip;
     p.opp_c = c.opponent_uct_c;
     p.uct_cap = c.arena_opponent == AZ_OPPONENT_UCT ? (uint32_t)(1 + (size_t)c.opponent_sims * p.maxc) : 0;
     p.need_per_move = (uint32_t)((c.n_playouts + 1) * p.maxc);
@@ -1428,6 +1430,40 @@ extern "C" int az_engine_opponent_moves(az_engine *e, void *stream) {
     if (e->cfg.game == AZ_GAME_CONNECT_FOUR) hipLaunchKernelGGL((az_opponent_kernel<AZG_CONNECT_FOUR>), grid, block, 0, (hipStream_t)stream, e->p);
     else hipLaunchKernelGGL((az_opponent_kernel<AZG_BREAKTHROUGH>), grid, block, 0, (hipStream_t)stream, e->p);
     HIPCHK(e, hipGetLastError());
+    return AZ_OK;
+}
+
+// two engines facing each other: slot g of a and of b play the same game; a move the one has played (it is in its record
+// store, and its root ply has moved past it) is handed to the other, which is waiting for exactly that ply
+__global__ void az_exchange_kernel(Params a, Params b) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.G) return;
+    if (a.phase[g] == PH_OPPONENT && b.ply[g] > a.ply[g]) {
+        a.opp_action[g] = (int)b.rec_move[(size_t)g * b.max_plies + a.ply[g]];
+        a.phase[g] = PH_OPP_DONE;
+    }
+    if (b.phase[g] == PH_OPPONENT && a.ply[g] > b.ply[g]) {
+        b.opp_action[g] = (int)a.rec_move[(size_t)g * a.max_plies + b.ply[g]];
+        b.phase[g] = PH_OPP_DONE;
+    }
+}
+
+extern "C" int az_engine_exchange_moves(az_engine *a, az_engine *b, void *stream) {
+    if (!a || !b) return AZ_E_INVALID;
+    if (a->p.opp_kind != AZ_OPPONENT_EXTERNAL || b->p.opp_kind != AZ_OPPONENT_EXTERNAL || a->p.G != b->p.G || a->p.game != b->p.game ||
+        a->p.geom.rows != b->p.geom.rows || a->p.geom.cols != b->p.geom.cols || a->p.arena_flip == b->p.arena_flip ||
+        a->cfg.device != b->cfg.device || a->n_games != b->n_games || a->n_games > a->p.G) {
+        a->err = "az_engine_exchange_moves: needs two AZ_OPPONENT_EXTERNAL engines of one game and device, equal n_slots, opposite "
+                 "arena_flip, reset with the same n_games <= n_slots";
+        return AZ_E_STATE;
+    }
+    if (!a->reset_done || !b->reset_done) {
+        a->err = "az_engine_exchange_moves before az_engine_reset";
+        return AZ_E_STATE;
+    }
+    HIPCHK(a, hipSetDevice(a->cfg.device));
+    hipLaunchKernelGGL(az_exchange_kernel, dim3((a->p.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, a->p, b->p);
+    HIPCHK(a, hipGetLastError());
     return AZ_OK;
 }
 

@@ -57,7 +57,7 @@ struct Params {
     const double *etas, *us;
     double *eta_buf; // [G][maxc] Dirichlet draw staged with the root request (Philox mode)
     // arena (evaluation games against a bot)
-    int arena_agent, opp_kind, opp_sims;
+    int arena_agent, opp_kind, opp_sims, arena_flip;
     double opp_c;
     int *opp_action;           // [G] the opponent bot's chosen move
     uint32_t uct_cap;          // UCT opponent: nodes per slot

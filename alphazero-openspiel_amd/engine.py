@@ -36,7 +36,7 @@ class SelfPlayEngine:
     def __init__(self, game_name, n_slots, n_playouts=100, c_puct=2.5, temperature=1.0, dirichlet_ratio=0.25,
                  use_dirichlet=True, keep_search_tree=True, backup="on-policy", max_games=None, device=0,
                  rng="philox", seed=0, nodes_per_slot=0, max_sims_per_tick=0, chain_window_us=0, manual_moves=False,
-                 dirichlet_alpha=0.3, arena_agent=None, opponent=None, opponent_sims=0, opponent_uct_c=1.0):
+                 dirichlet_alpha=0.3, arena_agent=None, opponent=None, opponent_sims=0, opponent_uct_c=1.0, arena_flip=False):
         self.lib = _lib.load()
         self.game = Game(game_name) if isinstance(game_name, str) else game_name
         self.device_index = _device_index(device)
@@ -68,6 +68,7 @@ class SelfPlayEngine:
         cfg.arena_opponent = _lib.OPPONENTS[opponent]
         cfg.opponent_sims = int(opponent_sims)
         cfg.opponent_uct_c = float(opponent_uct_c)
+        cfg.arena_flip = int(bool(arena_flip))
         self.cfg = cfg
         self.backup = backup
         self._h = C.c_void_p()
@@ -160,6 +161,10 @@ class SelfPlayEngine:
     def opponent_moves(self):
         """Arena engines: let the opponent bot choose its move in every slot where it is to move (applied by the next advance)."""
         self._check(self.lib.az_engine_opponent_moves(self._h, self._stream()))
+
+    def exchange_moves(self, other):
+        """Two engines facing each other (opponent="external", arena_flip False / True): pass on the moves just played."""
+        self._check(self.lib.az_engine_exchange_moves(self._h, other._h, self._stream()))
 
     def update_root(self, actions, keep_subtree=True):
         arr = (C.c_int32 * self.G)(*[int(a) for a in actions])

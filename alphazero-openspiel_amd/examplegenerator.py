@@ -23,9 +23,7 @@ _ENGINE_KW = ("n_playouts", "c_puct", "temperature", "dirichlet_ratio", "use_dir
 
 class ExampleGenerator:
     def __init__(self, net, game_name, device, n_pools=1, n_processes=1, **kwargs):
-        if kwargs.get("net2") is not None:
-            raise NotImplementedError("two-network pairings (net2 / test_zero_vs_zero, reference examplegenerator.py:88-90, "
-                                      "game_utils.py:120-145) are tournament tooling outside the path this package replaces")
+        self.net2 = copy.deepcopy(kwargs["net2"]) if kwargs.get("net2") is not None else None  # examplegenerator.py:88-90
         self.is_test = bool(kwargs.get("is_test", False))
         self.generate_statistics = bool(kwargs.get("generate_statistics", False))
         if self.generate_statistics:
@@ -123,8 +121,8 @@ class ExampleGenerator:
         name = getattr(game_fn, "__name__", str(game_fn))
         pairing = {"test_zero_vs_mcts": ("zero", "uct"), "test_net_vs_mcts": ("net", "uct"),
                    "test_zero_vs_random": ("zero", "random"), "test_net_vs_random": ("net", "random")}.get(name)
-        if pairing is None:
-            raise NotImplementedError("generate_tests supports the one-network pairings of game_utils.py:53-117, got %s" % name)
+        if pairing is None and name != "test_zero_vs_zero":
+            raise NotImplementedError("generate_tests supports the pairings of game_utils.py:53-145, got %s" % name)
         world, rank = azdist.world_size(), azdist.rank()
         n_local = int(n_games / world)
         if n_local < 1:
@@ -133,11 +131,24 @@ class ExampleGenerator:
             self.net = self.net.to(self.device)
             azdist.broadcast_net(self.net, src=0)
         kw = {k: self.kwargs[k] for k in ("n_playouts", "c_puct", "temperature") if k in self.kwargs}
-        s1, s2, self.last_progress = arena.play_tests(
-            self.net, self.game_name, n_local, pairing[0], pairing[1], opponent_sims=int(n_playouts_mcts), device=self.device,
-            seed=self.seed + 1000003 * self._generation + 7919 * rank, n_slots=self.n_slots, eval_backend=self.eval_backend,
-            eval_precision=self.eval_precision, **kw)
+        if name == "test_zero_vs_zero":  # two networks, each with its settings (game_utils.py:120-145; net2 defaults to net)
+            if world > 1 and self.net2 is not None:
+                self.net2 = self.net2.to(self.device)
+                azdist.broadcast_net(self.net2, src=0)
+            s1, s2, self.last_progress = arena.play_zero_vs_zero(
+                self.net, self.net2 if self.net2 is not None else self.net, self.game_name, n_local,
+                settings1=self.kwargs.get("settings1", kw), settings2=self.kwargs.get("settings2", kw), device=self.device,
+                seed=self.seed + 1000003 * self._generation + 7919 * rank, eval_backend=self.eval_backend,
+                eval_precision=self.eval_precision)
+        else:
+            s1, s2, self.last_progress = self._play_tests(arena, n_local, pairing, n_playouts_mcts, rank, kw)
         self._generation += 1
         total = torch.tensor([float(s1.sum() + s2.sum()), float(2 * n_local)], dtype=torch.float64)
         total = azdist.all_reduce_sum(total, self.device)
         return float(total[0] / total[1])
+
+    def _play_tests(self, arena, n_local, pairing, n_playouts_mcts, rank, kw):
+        return arena.play_tests(
+            self.net, self.game_name, n_local, pairing[0], pairing[1], opponent_sims=int(n_playouts_mcts), device=self.device,
+            seed=self.seed + 1000003 * self._generation + 7919 * rank, n_slots=self.n_slots, eval_backend=self.eval_backend,
+            eval_precision=self.eval_precision, **kw)

@@ -3,8 +3,8 @@ the AlphaZeroBot façade (search on the GPU, one engine slot).  Bulk generation 
 ExampleGenerator, which keeps thousands of games on the device; this entry exists for drop-in parity
 (same arguments, same example records, same numpy random stream).
 
-The evaluation pairings `test_zero_vs_mcts`, `test_net_vs_mcts`, `test_zero_vs_random`, `test_net_vs_random`
-(game_utils.py:53-128) keep their signatures and return shapes; each call plays its two games on the device arena
+The evaluation pairings `test_zero_vs_mcts`, `test_net_vs_mcts`, `test_zero_vs_random`, `test_net_vs_random`,
+`test_zero_vs_zero` (game_utils.py:53-145) keep their signatures and return shapes; each call plays its two games on the device arena
 (alphazero_openspiel_amd.arena).  `ExampleGenerator(is_test=True).generate_tests` runs n of them as one batch."""
 import numpy as np
 
@@ -85,5 +85,17 @@ def test_net_vs_random(policy_fn, game_name, **kwargs):
     return _one_test(policy_fn, game_name, "net", "random", 0, kwargs)
 
 
-for _f in (test_zero_vs_mcts, test_net_vs_mcts, test_zero_vs_random, test_net_vs_random):
+def test_zero_vs_zero(policy_fn, max_search_nodes, game_name, policy_fn2=None, generate_statistics=False, **kwargs):
+    """Two AlphaZeroBots (root noise on) with their own networks and `settings1` / `settings2`, each once as first player
+    -> (score1, score2, statistics) from the first network's point of view (game_utils.py:120-145).  `max_search_nodes` is
+    unused, as in the reference.  generate_statistics (deep copies of both search trees after every move) is not built."""
+    if generate_statistics:
+        raise NotImplementedError("generate_statistics is not built")
+    from . import arena
+    s1, s2, _ = arena.play_zero_vs_zero(policy_fn, policy_fn2, game_name, 1, settings1=kwargs.get("settings1"),
+                                        settings2=kwargs.get("settings2"))
+    return float(s1[0]), float(s2[0]), {}
+
+
+for _f in (test_zero_vs_mcts, test_net_vs_mcts, test_zero_vs_random, test_net_vs_random, test_zero_vs_zero):
     _f.__test__ = False  # reference names; not pytest cases

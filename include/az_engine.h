@@ -95,7 +95,7 @@ typedef struct az_config {
     int32_t arena_agent;    /* AZ_ARENA_* */
     int32_t arena_opponent; /* AZ_OPPONENT_* */
     int32_t opponent_sims;  /* AZ_OPPONENT_UCT: max_search_nodes of mcts.MCTSBot (game_utils.py:74-75) */
-    int32_t reserved_arena;
+    int32_t arena_flip;     /* 1: the agent takes the OTHER side, (i & 1) ^ 1 - the second network of a two-engine pairing */
     double opponent_uct_c;  /* AZ_OPPONENT_UCT: uct_c (1 in the reference's calls) */
 } az_config;
 
@@ -109,6 +109,8 @@ typedef struct az_config {
 #define AZ_OPPONENT_UCT 2    /* open_spiel.python.algorithms.mcts.MCTSBot(game, player, uct_c, max_search_nodes,
                                 RandomRolloutEvaluator(1)) - third party, absent from the reference tree, version unpinned:
                                 restated from its published algorithm */
+#define AZ_OPPONENT_EXTERNAL 3 /* the opponent's moves come from ANOTHER engine (az_engine_exchange_moves): two AlphaZero agents with
+                                  their own networks and settings - test_zero_vs_zero (game_utils.py:120-145) */
 
 typedef struct az_sizes {
     int32_t num_actions;  /* A   = game.num_distinct_actions() */
@@ -209,6 +211,11 @@ int az_engine_advance_slots(az_engine *e, int32_t first_slot, int32_t n_slots, c
  * a uniformly random legal action, or a UCT search with random rollouts).  The next az_engine_advance applies the moves.
  * One arena tick = az_engine_advance, az_engine_opponent_moves, PV-net forward.  Asynchronous on `stream`. */
 int az_engine_opponent_moves(az_engine *e, void *stream);
+
+/* Two arena engines facing each other (both AZ_OPPONENT_EXTERNAL, same game, same n_slots, arena_flip 0 and 1, games = slots:
+ * no refill): for every slot, hand a's agent move to b and b's to a as soon as it has been played.  One tick of such a
+ * pairing = advance(a), advance(b), az_engine_exchange_moves(a, b), forward(net of a), forward(net of b). */
+int az_engine_exchange_moves(az_engine *a, az_engine *b, void *stream);
 
 /* MCTS.update_root(action) (mcts.py:192-203) for every slot, manual_moves engines only: applies
  * actions[g] (host array [G]; AZ_ACTION_NONE = leave the slot alone) to the slot's root state, keeps the chosen

@@ -910,5 +910,40 @@ int orc_opponent_action(const orc_state *s, int opponent, int n_sims, double uct
     return opponent == ORC_OPPONENT_RANDOM ? random_legal_action(s, &r) : uct_bot_action(s, n_sims, uct_c, &r);
 }
 
+
+/* test_zero_vs_zero (game_utils.py:120-145) for ONE game: two AlphaZeroBots outside self-play, each with its own policy
+ * function and settings; bot 1 plays side game_id & 1.  Root noise off (the device draws its noise from a fast-math gamma
+ * sampler that a CPU cannot reproduce bit for bit; with noise the pairing is compared statistically). */
+typedef struct {
+    int32_t game, rows, cols, game_id;
+    int32_t n_playouts1, n_playouts2, keep_search_tree, reserved;
+    double c_puct1, c_puct2, temperature;
+} orc_duel_cfg;
+int orc_play_duel_game(const orc_duel_cfg *cfg, orc_policy_fn fn1, orc_policy_fn fn2, void *user, int32_t *actions, int max_actions,
+                       double *ret0) {
+    orc_state s;
+    orc_state_init(&s, cfg->game, cfg->rows, cfg->cols);
+    int A = orc_num_actions(cfg->game, cfg->rows, cfg->cols);
+    orc_bot *b1 = orc_bot_new(A, 0, cfg->keep_search_tree, cfg->temperature, cfg->c_puct1, cfg->n_playouts1, 0, 0.25, 1, fn1, user);
+    orc_bot *b2 = orc_bot_new(A, 0, cfg->keep_search_tree, cfg->temperature, cfg->c_puct2, cfg->n_playouts2, 0, 0.25, 1, fn2, user);
+    double *pol = (double *)malloc(sizeof(double) * (size_t)A);
+    int n = 0;
+    while (!s.terminal) {
+        orc_bot *b = ((s.nhist & 1) == (cfg->game_id & 1)) ? b1 : b2;
+        int action = orc_bot_step(b, &s, NULL, 0.0, pol);
+        if (n >= max_actions) {
+            n = -1;
+            break;
+        }
+        actions[n++] = action;
+        orc_apply_action(&s, action);
+    }
+    *ret0 = s.ret0;
+    orc_bot_free(b1);
+    orc_bot_free(b2);
+    free(pol);
+    return n;
+}
+
 int64_t orc_nodes_alive(void) { return g_nodes_alive; }
 int64_t orc_nodes_total(void) { return g_nodes_total; }

@@ -34,6 +34,12 @@ class ArenaCfg(C.Structure):
                 ("game_id", C.c_int32), ("reserved", C.c_int32)]
 
 
+class DuelCfg(C.Structure):
+    _fields_ = [("game", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("game_id", C.c_int32),
+                ("n_playouts1", C.c_int32), ("n_playouts2", C.c_int32), ("keep_search_tree", C.c_int32), ("reserved", C.c_int32),
+                ("c_puct1", C.c_double), ("c_puct2", C.c_double), ("temperature", C.c_double)]
+
+
 ARENA_AGENTS = {"zero": 1, "net": 2}
 OPPONENTS = {"random": 1, "uct": 2}
 
@@ -81,6 +87,7 @@ def lib():
     L.orc_play_game_self.argtypes = [C.POINTER(SelfplayCfg), POLICY_FN, vp, dp, C.c_int, dp, C.c_int,
                                      dp, dp, dp, ip, lp, C.c_int, dp, lp]
     L.orc_play_arena_game.argtypes = [C.POINTER(ArenaCfg), POLICY_FN, vp, ip, C.c_int, dp]
+    L.orc_play_duel_game.argtypes = [C.POINTER(DuelCfg), POLICY_FN, POLICY_FN, vp, ip, C.c_int, dp]
     L.orc_opponent_action.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_int32]
     L.orc_nodes_alive.restype = C.c_int64
     L.orc_nodes_total.restype = C.c_int64
@@ -320,3 +327,20 @@ def play_arena_game(py_policy, game_name, game_id, agent="zero", opponent="uct",
 
 def opponent_action(state, opponent, n_sims, uct_c, seed, game_id):
     return lib().orc_opponent_action(state.ptr, OPPONENTS[opponent], int(n_sims), float(uct_c), int(seed), int(game_id))
+
+
+def play_duel_game(py_policy1, py_policy2, game_name, game_id, n_playouts1=100, n_playouts2=100, c_puct1=2.5, c_puct2=2.5,
+                   temperature=1.0):
+    """test_zero_vs_zero's play_game through the C restatement (root noise off): bot 1 plays side game_id & 1."""
+    L = lib()
+    g, r, c = parse_game(game_name)
+    A = L.orc_num_actions(g, r, c)
+    cfg = DuelCfg(g, r, c, int(game_id), n_playouts1, n_playouts2, 1, 0, c_puct1, c_puct2, temperature)
+    cb1, cb2 = wrap_policy(py_policy1, A, 4 * r * c), wrap_policy(py_policy2, A, 4 * r * c)
+    mp = max_plies(g, r, c)
+    actions = np.zeros(mp, dtype=np.int32)
+    ret0 = np.zeros(1, dtype=np.float64)
+    n = L.orc_play_duel_game(C.byref(cfg), cb1, cb2, None, _ip(actions), mp, _dp(ret0))
+    if n < 0:
+        raise RuntimeError("oracle duel overflow")
+    return {"actions": actions[:n].tolist(), "ret0": float(ret0[0])}

@@ -83,6 +83,52 @@ def test_generate_tests_and_the_reference_pairings():
     assert len(out) == 2 and all(v in (-1.0, 0.0, 1.0) for v in out)
 
 
+@pytest.mark.parametrize("game_name,S1,S2", [("connect_four", 24, 12), ("breakthrough(rows=6,columns=6)", 10, 16)])
+def test_two_engine_duel_equals_the_oracle(game_name, S1, S2):
+    """test_zero_vs_zero (game_utils.py:120-145): two AlphaZero agents with their own evaluators and settings, one engine each,
+    moves handed over by az_engine_exchange_moves.  Root noise off: the games equal the oracle's two-bot games move for move."""
+    from alphazero_openspiel_amd import arena, engine as E
+    n_games = 10
+    kw = dict(max_games=n_games, device=0, use_dirichlet=False, arena_agent="zero", opponent="external")
+    ea = E.SelfPlayEngine(game_name, n_games, n_playouts=S1, c_puct=2.5, seed=1, arena_flip=False, **kw)
+    eb = E.SelfPlayEngine(game_name, n_games, n_playouts=S2, c_puct=1.5, seed=2, arena_flip=True, **kw)
+    A = ea.A
+    eva = E.HostPolicyEvaluator(ea, lambda b: fakepolicy.fake_eval(b, A, 3))
+    evb = E.HostPolicyEvaluator(eb, lambda b: fakepolicy.fake_eval(b, A, 8))
+    ret0, prog, ex = arena.run_duel(ea, eb, eva, evb, n_games, use_graph=False, check_every=4)
+    ea.close()
+    eb.close()
+    assert prog["error_flags"] == 0
+    for gid in range(n_games):
+        want = orc.play_duel_game(lambda b: fakepolicy.fake_eval(b, A, 3), lambda b: fakepolicy.fake_eval(b, A, 8), game_name, gid,
+                                  n_playouts1=S1, n_playouts2=S2, c_puct1=2.5, c_puct2=1.5)
+        n = int(ex["game_len"][gid])
+        assert ex["move"][gid, :n].tolist() == want["actions"], gid
+        assert float(ret0[gid]) == want["ret0"]
+
+
+def test_zero_vs_zero_entry_points():
+    from alphazero_openspiel_amd import arena, game_utils
+    from alphazero_openspiel_amd.examplegenerator import ExampleGenerator
+    from alphazero_openspiel_amd.network import Net
+    strong = _ckpt("connect_four", [3, 6, 7], 7).cuda()
+    torch.manual_seed(0)
+    weak = Net([3, 6, 7], 7).cuda()          # untrained
+    s1, s2, prog = arena.play_zero_vs_zero(strong, weak, "connect_four", 64, settings1=dict(n_playouts=50), settings2=dict(n_playouts=50),
+                                           device="cuda:0", seed=5)
+    assert prog["error_flags"] == 0 and float((s1.sum() + s2.sum()) / 128) > 0.5      # the trained network wins
+    s1, s2, _ = arena.play_zero_vs_zero(strong, None, "connect_four", 32, settings1=dict(n_playouts=30), settings2=dict(n_playouts=30),
+                                        device="cuda:0", seed=6)
+    assert abs(float((s1.sum() + s2.sum()) / 64)) < 0.6                                 # against itself: no systematic winner
+    gen = ExampleGenerator(strong, "connect_four", torch.device("cuda:0"), is_test=True, net2=weak, seed=7,
+                           settings1=dict(n_playouts=30), settings2=dict(n_playouts=30))
+    avg = gen.generate_tests(16, game_utils.test_zero_vs_zero, 0)
+    assert -1.0 <= avg <= 1.0 and avg > 0.0
+    out = game_utils.test_zero_vs_zero(strong.predict, 0, "connect_four", policy_fn2=weak.predict,
+                                       settings1=dict(n_playouts=20), settings2=dict(n_playouts=20))
+    assert len(out) == 3 and out[2] == {} and all(v in (-1.0, 0.0, 1.0) for v in out[:2])
+
+
 def test_arena_configuration_errors():
     from alphazero_openspiel_amd import engine as E
     with pytest.raises(E.EngineError):
