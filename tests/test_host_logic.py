@@ -190,7 +190,7 @@ def test_engine_refuses_cpu_devices():
     with pytest.raises(EngineError):
         ExampleGenerator(Net([3, 6, 7], 7), "connect_four", torch.device("cpu"))
     with pytest.raises(NotImplementedError):
-        ExampleGenerator(Net([3, 6, 7], 7), "connect_four", torch.device("cuda:0"), net2=Net([3, 6, 7], 7))
+        ExampleGenerator(Net([3, 6, 7], 7), "connect_four", torch.device("cuda:0"), generate_statistics=True)
 
 
 # ------------------------------------------------------------------------------------- multi-rank (gloo)
