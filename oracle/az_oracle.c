@@ -842,6 +842,20 @@ static int uct_bot_action(const orc_state *root_state, int n_sims, double uct_c,
     return action;
 }
 
+/* NeuralNetBot.step (alphazerobot.py:105-120): argmax (first maximum) of the masked, renormalised network priors */
+static int net_bot_step(orc_policy_fn fn, void *user, const orc_state *s, int A, double *pol, double *board) {
+    double v;
+    orc_state_to_board(s, board);
+    fn(user, s, board, pol, &v);
+    int32_t legal[ORC_MAX_CELLS * 3];
+    int nl = orc_legal_actions(s, legal);
+    orc_remove_illegal_actions(pol, A, legal, nl);
+    int action = 0;
+    for (int a = 1; a < A; a++)
+        if (pol[a] > pol[action]) action = a;
+    return action;
+}
+
 #define ORC_ARENA_ZERO 1
 #define ORC_ARENA_NET 2
 #define ORC_OPPONENT_RANDOM 1
@@ -872,16 +886,8 @@ int orc_play_arena_game(const orc_arena_cfg *cfg, orc_policy_fn fn, void *user, 
         if ((s.nhist & 1) == (cfg->game_id & 1)) { /* the agent's turn */
             if (cfg->agent == ORC_ARENA_ZERO) {
                 action = orc_bot_step(bot, &s, NULL, 0.0, pol);
-            } else { /* NeuralNetBot.step */
-                double v;
-                orc_state_to_board(&s, board);
-                fn(user, &s, board, pol, &v);
-                int32_t legal[ORC_MAX_CELLS * 3];
-                int nl = orc_legal_actions(&s, legal);
-                orc_remove_illegal_actions(pol, A, legal, nl);
-                action = 0;
-                for (int a = 1; a < A; a++)
-                    if (pol[a] > pol[action]) action = a;
+            } else {
+                action = net_bot_step(fn, user, &s, A, pol, board);
             }
         } else {
             orc_philox r;
@@ -918,6 +924,7 @@ typedef struct {
     int32_t game, rows, cols, game_id;
     int32_t n_playouts1, n_playouts2, keep_search_tree, reserved;
     double c_puct1, c_puct2, temperature;
+    int32_t agent1, agent2; /* ORC_ARENA_ZERO (AlphaZeroBot) or ORC_ARENA_NET (NeuralNetBot) */
 } orc_duel_cfg;
 int orc_play_duel_game(const orc_duel_cfg *cfg, orc_policy_fn fn1, orc_policy_fn fn2, void *user, int32_t *actions, int max_actions,
                        double *ret0) {
@@ -926,11 +933,13 @@ int orc_play_duel_game(const orc_duel_cfg *cfg, orc_policy_fn fn1, orc_policy_fn
     int A = orc_num_actions(cfg->game, cfg->rows, cfg->cols);
     orc_bot *b1 = orc_bot_new(A, 0, cfg->keep_search_tree, cfg->temperature, cfg->c_puct1, cfg->n_playouts1, 0, 0.25, 1, fn1, user);
     orc_bot *b2 = orc_bot_new(A, 0, cfg->keep_search_tree, cfg->temperature, cfg->c_puct2, cfg->n_playouts2, 0, 0.25, 1, fn2, user);
-    double *pol = (double *)malloc(sizeof(double) * (size_t)A);
+    double *pol = (double *)malloc(sizeof(double) * (size_t)A), *board = (double *)malloc(sizeof(double) * 4 * ORC_MAX_CELLS);
     int n = 0;
     while (!s.terminal) {
-        orc_bot *b = ((s.nhist & 1) == (cfg->game_id & 1)) ? b1 : b2;
-        int action = orc_bot_step(b, &s, NULL, 0.0, pol);
+        const int first = (s.nhist & 1) == (cfg->game_id & 1);
+        orc_bot *b = first ? b1 : b2;
+        int action = (first ? cfg->agent1 : cfg->agent2) == ORC_ARENA_NET ? net_bot_step(first ? fn1 : fn2, user, &s, A, pol, board)
+                                                                        : orc_bot_step(b, &s, NULL, 0.0, pol);
         if (n >= max_actions) {
             n = -1;
             break;
@@ -942,6 +951,7 @@ int orc_play_duel_game(const orc_duel_cfg *cfg, orc_policy_fn fn1, orc_policy_fn
     orc_bot_free(b1);
     orc_bot_free(b2);
     free(pol);
+    free(board);
     return n;
 }
 

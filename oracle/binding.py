@@ -37,7 +37,8 @@ class ArenaCfg(C.Structure):
 class DuelCfg(C.Structure):
     _fields_ = [("game", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("game_id", C.c_int32),
                 ("n_playouts1", C.c_int32), ("n_playouts2", C.c_int32), ("keep_search_tree", C.c_int32), ("reserved", C.c_int32),
-                ("c_puct1", C.c_double), ("c_puct2", C.c_double), ("temperature", C.c_double)]
+                ("c_puct1", C.c_double), ("c_puct2", C.c_double), ("temperature", C.c_double),
+                ("agent1", C.c_int32), ("agent2", C.c_int32)]
 
 
 ARENA_AGENTS = {"zero": 1, "net": 2}
@@ -330,12 +331,13 @@ def opponent_action(state, opponent, n_sims, uct_c, seed, game_id):
 
 
 def play_duel_game(py_policy1, py_policy2, game_name, game_id, n_playouts1=100, n_playouts2=100, c_puct1=2.5, c_puct2=2.5,
-                   temperature=1.0):
+                   temperature=1.0, agent1="zero", agent2="zero"):
     """test_zero_vs_zero's play_game through the C restatement (root noise off): bot 1 plays side game_id & 1."""
     L = lib()
     g, r, c = parse_game(game_name)
     A = L.orc_num_actions(g, r, c)
-    cfg = DuelCfg(g, r, c, int(game_id), n_playouts1, n_playouts2, 1, 0, c_puct1, c_puct2, temperature)
+    cfg = DuelCfg(g, r, c, int(game_id), n_playouts1, n_playouts2, 1, 0, c_puct1, c_puct2, temperature,
+                  ARENA_AGENTS[agent1], ARENA_AGENTS[agent2])
     cb1, cb2 = wrap_policy(py_policy1, A, 4 * r * c), wrap_policy(py_policy2, A, 4 * r * c)
     mp = max_plies(g, r, c)
     actions = np.zeros(mp, dtype=np.int32)

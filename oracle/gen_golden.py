@@ -19,6 +19,9 @@ oracle/fakepolicy.py as policy_fn):
                       as .npz (data fixture; lets the GPU box run the same net)
   replay.json         Trainer.remove_duplicates over two generations + FIFO trim, the net_step batch gather and one
                       net_step update (train.py:95-130,156-201,226-236)
+  arena.json          game_utils.play_game between the reference's AlphaZeroBot (outside self-play) and NeuralNetBot
+                      instances with different policy functions / settings, both seatings (game_utils.py:16-35,
+                      alphazerobot.py:42-120)
   rules_*.json        random playouts of oracle/pygames.py (NOT reference output:
                       OpenSpiel is absent; rules are "parity unpinned")
 
@@ -367,6 +370,44 @@ def gen_replay(ref):
             "n_games_buffer": n_games_buffer, "dedupe1": snap1, "dedupe2": snap2, "batch": batch, "net_step": step}
 
 
+def gen_arena(ref):
+    """game_utils.play_game (game_utils.py:16-35) between the reference's own bots OUTSIDE self-play: AlphaZeroBot
+    (use_dirichlet=False, as the test_*_vs_mcts pairings construct it: alphazerobot.py:42-93 with the two-move re-rooting and
+    the greedy move) and NeuralNetBot (alphazerobot.py:96-120), each with its own policy function and settings, each pairing
+    played with bot 1 as first and as second player.  The opponents of the reference's test functions themselves (OpenSpiel's
+    MCTSBot / random bot) are absent here; these games pin the AGENT side of the arena."""
+    AZB, NNB = ref.alphazerobot.AlphaZeroBot, ref.alphazerobot.NeuralNetBot
+    out = []
+    specs = [("connect_four", ("zero", "zero"), 24, 12, 2.5, 1.5, 3, 8),
+             ("connect_four", ("net", "zero"), 1, 16, 2.5, 2.5, 5, 6),
+             ("connect_four", ("zero", "net"), 20, 1, 3.0, 2.5, 7, 9),
+             ("breakthrough(rows=6,columns=6)", ("zero", "zero"), 10, 16, 2.5, 1.5, 3, 8),
+             ("breakthrough(rows=5,columns=4)", ("net", "zero"), 1, 12, 2.5, 2.5, 2, 4)]
+    for game_name, kinds, S1, S2, c1, c2, salt1, salt2 in specs:
+        game = pygames.load_game(game_name)
+        A = game.num_distinct_actions()
+        shape = game.information_state_normalized_vector_shape()
+        pfs = [fakepolicy.make_policy_fn(ref.network.state_to_board, shape, A, salt) for salt in (salt1, salt2)]
+        for first in (0, 1):  # the side bot 1 plays
+            def make(kind, player, pf, S, c):
+                return AZB(game, player, pf, use_dirichlet=False, n_playouts=S, c_puct=c) if kind == "zero" else NNB(game, player, pf)
+            b1 = make(kinds[0], first, pfs[0], S1, c1)
+            b2 = make(kinds[1], 1 - first, pfs[1], S2, c2)
+            moves = []
+            for b in (b1, b2):
+                orig = b.step
+
+                def step(state, _orig=orig):
+                    policy, action = _orig(state)
+                    moves.append(int(action))
+                    return policy, action
+                b.step = step
+            ret0 = ref.game_utils.play_game(game, b1 if first == 0 else b2, b2 if first == 0 else b1)
+            out.append({"game": game_name, "agents": list(kinds), "bot1_side": first, "n_playouts": [S1, S2], "c_puct": [c1, c2],
+                        "salts": [salt1, salt2], "actions": moves, "ret0": float(ret0)})
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_harness.load_reference()
@@ -383,6 +424,7 @@ def main():
         dump("rules_%s.json" % tag, blob)
     print("net_forward:", gen_net_forward(ref))
     dump("replay.json", gen_replay(ref))
+    dump("arena.json", gen_arena(ref))
 
 
 if __name__ == "__main__":

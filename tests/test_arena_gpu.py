@@ -107,6 +107,31 @@ def test_two_engine_duel_equals_the_oracle(game_name, S1, S2):
         assert float(ret0[gid]) == want["ret0"]
 
 
+@pytest.mark.parametrize("pair", range(5))
+def test_device_duels_equal_the_games_of_the_reference_bots(pair):
+    """tests/golden/arena.json (produced by the REAL reference: play_game between its AlphaZeroBot / NeuralNetBot instances,
+    both seatings): two device arena engines facing each other reproduce those games move for move."""
+    from conftest import load_golden
+    from alphazero_openspiel_amd import arena, engine as E
+    c0, c1 = load_golden("arena.json")[2 * pair: 2 * pair + 2]
+    assert c0["bot1_side"] == 0 and c1["bot1_side"] == 1 and c0["game"] == c1["game"]
+    engines = []
+    for flip in (0, 1):
+        kind = c0["agents"][flip]
+        kw = dict(n_playouts=1, keep_search_tree=False) if kind == "net" else dict(n_playouts=c0["n_playouts"][flip], c_puct=c0["c_puct"][flip])
+        engines.append(E.SelfPlayEngine(c0["game"], 2, max_games=2, device=0, use_dirichlet=False, arena_agent=kind, opponent="external",
+                                        arena_flip=bool(flip), seed=flip, **kw))
+    A = engines[0].A
+    evs = [E.HostPolicyEvaluator(engines[i], (lambda salt: (lambda b: fakepolicy.fake_eval(b, A, salt)))(c0["salts"][i])) for i in (0, 1)]
+    ret0, prog, ex = arena.run_duel(engines[0], engines[1], evs[0], evs[1], 2, use_graph=False, check_every=2)
+    for e in engines:
+        e.close()
+    for gid, want in enumerate((c0, c1)):
+        n = int(ex["game_len"][gid])
+        assert ex["move"][gid, :n].tolist() == want["actions"], (pair, gid)
+        assert float(ret0[gid]) == want["ret0"]
+
+
 def test_zero_vs_zero_entry_points():
     from alphazero_openspiel_amd import arena, game_utils
     from alphazero_openspiel_amd.examplegenerator import ExampleGenerator

@@ -105,3 +105,17 @@ def test_no_node_leak():
     before = L.orc_nodes_alive()
     orc.play_game_self(_policy(7, 5), "connect_four", n_playouts=20, seed=3)
     assert L.orc_nodes_alive() == before
+
+
+@pytest.mark.parametrize("idx", range(10))
+def test_arena_games_between_reference_bots(idx):
+    """tests/golden/arena.json: game_utils.play_game between the reference's AlphaZeroBot (outside self-play: two-move
+    re-rooting, greedy move) and NeuralNetBot instances, both seatings - reproduced by the oracle's two-bot game."""
+    c = load_golden("arena.json")[idx]
+    g, r, cc = orc.parse_game(c["game"])
+    A = orc.lib().orc_num_actions(g, r, cc)
+    p1 = lambda b: fakepolicy.fake_eval(b, A, c["salts"][0])
+    p2 = lambda b: fakepolicy.fake_eval(b, A, c["salts"][1])
+    got = orc.play_duel_game(p1, p2, c["game"], c["bot1_side"], n_playouts1=c["n_playouts"][0], n_playouts2=c["n_playouts"][1],
+                             c_puct1=c["c_puct"][0], c_puct2=c["c_puct"][1], agent1=c["agents"][0], agent2=c["agents"][1])
+    assert got["actions"] == c["actions"] and got["ret0"] == c["ret0"]
