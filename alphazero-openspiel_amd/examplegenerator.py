@@ -35,7 +35,8 @@ class ExampleGenerator:
         self.net = copy.deepcopy(net)  # examplegenerator.py:86: a frozen copy of the current net
         self.game_name = game_name
         self.game = Game(game_name)
-        self.n_pools, self.n_processes = n_pools, n_processes  # accepted for signature parity; see module doc
+        self.n_pools, self.n_processes = int(n_pools), n_processes  # no pools / worker processes here (module doc); n_pools only
+                                                                    # reproduces the reference's game COUNT
         self.kwargs = kwargs
         # engine extensions (not reference keywords)
         self.n_slots = kwargs.get("n_slots")           # concurrent games per GPU; default min(n_games, 4096)
@@ -57,9 +58,12 @@ class ExampleGenerator:
         """This rank's shard of the generation on the HIP engine, then the generation-end exchange on DEVICE buffers.
         -> (gathered uint8 device tensor [world * nbytes], nbytes per rank, games per rank, world, (max_plies, max_children))"""
         world, rank = azdist.world_size(), azdist.rank()
-        n_local = int(n_games / world)
+        if world == 1:  # the reference plays int(n_games / n_pools) games in each of its n_pools pools (examplegenerator.py:149):
+            n_local = int(n_games / self.n_pools) * self.n_pools if self.n_pools > 1 else int(n_games)  # same count here
+        else:
+            n_local = int(n_games / world)
         if n_local < 1:
-            raise ValueError("n_games=%d is fewer than the %d ranks" % (n_games, world))
+            raise ValueError("n_games=%d is fewer than the %d ranks / pools" % (n_games, max(world, self.n_pools)))
         if world > 1:
             # every handler gets a copy of THE current net (examplegenerator.py:121): the training rank's weights and
             # BatchNorm statistics, whatever this rank was constructed with
