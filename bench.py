@@ -272,7 +272,7 @@ def main():
             raise SystemExit("--overlap needs --net fused")
         group_nets = [FusedNet(net.eval(), device, max_boards=n, precision=args.precision) for _, n in E.slot_groups(G, args.overlap)]
         tk = E.OverlappedTicker(eng, group_nets, args.overlap, use_graph=not args.no_graph, io=(obs, pri, val))
-        tick, sync_groups, graph = tk.tick, tk.synchronize, (tk.graphs or None)
+        tick, sync_groups, graph, tpg = tk.tick, tk.synchronize, (tk.graphs or None), 1  # (one tick per group graph)
 
     def barrier():
         if world > 1:
