@@ -11,8 +11,19 @@ import torch
 import torch.distributed as dist
 
 
+import os
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _single():
+    """True when no collective is needed.  AZ_DIST_FORCE=1 makes a one-rank process group run every collective anyway: the
+    RCCL code path (device buffers, dtypes, barriers) can then be exercised on a box with a single GPU."""
+    if dist.is_available() and dist.is_initialized() and os.environ.get("AZ_DIST_FORCE") == "1":
+        return False
+    return world_size() == 1
 
 
 def rank():
@@ -67,7 +78,7 @@ def all_gather_exports(payload, device=None):
     """Every rank contributes its packed records; every rank gets the list of all exports (rank order).
     Two collectives: all_gather of the byte counts, then all_gather of the buffers padded to the maximum
     (RCCL has no all-gather-v)."""
-    if world_size() == 1:
+    if _single():
         return [unpack_export(payload)]
     backend = dist.get_backend()
     dev = torch.device(device) if (backend == "nccl" and device is not None) else torch.device("cpu")
@@ -88,7 +99,7 @@ def all_gather_device_exports(buf):
     (same size on every rank: same game, same games per rank), every rank receives all of them, rank order, as ONE tensor
     of world * nbytes.  Backend nccl (= RCCL over xGMI): the buffers never leave HBM.  gloo (CPU rehearsal): staged through
     host memory and returned on the input's device."""
-    if world_size() == 1:
+    if _single():
         return buf
     if dist.get_backend() == "nccl":
         out = torch.empty(world_size() * buf.numel(), dtype=torch.uint8, device=buf.device)
@@ -102,7 +113,7 @@ def all_gather_device_exports(buf):
 
 def all_reduce_sum(t, device=None):
     """Sum a small CPU tensor over the ranks (on the rank's GPU when the backend is nccl)."""
-    if world_size() == 1:
+    if _single():
         return t
     if dist.get_backend() == "nccl":
         d = t.to(device)
@@ -116,7 +127,7 @@ def broadcast_net(net, src=0):
     """Weights + BN buffers from the training rank to every self-play rank at generation start
     (replaces the deepcopy handed to each handle_gpu process, reference examplegenerator.py:121).  One flat fp32
     buffer, one broadcast (RCCL when the backend is nccl: the module must then live on this rank's GPU)."""
-    if world_size() == 1:
+    if _single():
         return
     tensors = list(net.parameters()) + list(net.buffers())
     flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])

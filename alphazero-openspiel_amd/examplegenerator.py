@@ -64,7 +64,7 @@ class ExampleGenerator:
             n_local = int(n_games / world)
         if n_local < 1:
             raise ValueError("n_games=%d is fewer than the %d ranks / pools" % (n_games, max(world, self.n_pools)))
-        if world > 1:
+        if world > 1 or not azdist._single():
             # every handler gets a copy of THE current net (examplegenerator.py:121): the training rank's weights and
             # BatchNorm statistics, whatever this rank was constructed with
             self.net = self.net.to(self.device)

@@ -197,7 +197,9 @@ def main():
     local_rank = local_rank % max(1, torch.cuda.device_count())  # rehearsal: several ranks may share one GPU (gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # AZ_DIST_FORCE=1: run the collectives of the N > 1 path in a one-rank process group (RCCL on a single-GPU box)
+    distributed = world > 1 or os.environ.get("AZ_DIST_FORCE") == "1"
+    if distributed:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)  # RCCL communicator bound to this rank's GPU
@@ -222,7 +224,7 @@ def main():
         args.blocks, args.filters = net.n_blocks, net.n_filts
     else:
         net = Net(game.information_state_normalized_vector_shape(), A, n_blocks=args.blocks, n_filters=args.filters)
-    if world > 1:  # the path's first collective: every rank takes the training rank's weights (examplegenerator.py:121)
+    if distributed:  # the path's first collective: every rank takes the training rank's weights (examplegenerator.py:121)
         net = net.to(device)
         azdist.broadcast_net(net, src=0)
     if args.net == "fused":
@@ -275,7 +277,7 @@ def main():
         tick, sync_groups, graph, tpg = tk.tick, tk.synchronize, (tk.graphs or None), 1  # (one tick per group graph)
 
     def barrier():
-        if world > 1:
+        if distributed:
             if args.backend == "nccl":
                 dist.barrier(device_ids=[local_rank])
             else:
@@ -306,7 +308,7 @@ def main():
     p1, ticks = run_until((Wm + K) * G)
     t_ag0 = time.perf_counter()
     allgather_ms = None
-    if world > 1:  # generation-end exchange of the finished-game records (the path's only collective)
+    if distributed:  # generation-end exchange of the finished-game records (the path's only collective)
         buf = eng.export_device()  # packed records, device resident
         gathered = azdist.all_gather_device_exports(buf)  # RCCL all-gather over xGMI (nccl backend)
         torch.cuda.synchronize(device)
@@ -322,7 +324,7 @@ def main():
     moves = p1["moves"] - p0["moves"]
     tot = torch.tensor([dt, float(games), float(sims), float(evals), float(moves)], dtype=torch.float64,
                        device=device if args.backend == "nccl" else "cpu")
-    if world > 1:
+    if distributed:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -466,7 +468,7 @@ def main():
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

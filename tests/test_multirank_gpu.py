@@ -61,3 +61,57 @@ def test_example_generator_shards_games_over_ranks(tmp_path):
     assert a["n_unique"] == b["n_unique"] > 8 and a["r_digest"] == b["r_digest"]     # both device stores hold the same records
     assert a["digest"] == b["digest"]                       # every rank holds the same gathered generation
     assert a["first_moves"][:6] != a["first_moves"][6:]     # the two shards are different games (different RNG streams)
+
+
+_NCCL_WORKER = r"""
+import json, os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+from alphazero_openspiel_amd import distributed as azdist
+from alphazero_openspiel_amd.examplegenerator import ExampleGenerator
+from alphazero_openspiel_amd.network import load_npz_checkpoint
+from alphazero_openspiel_amd.replay import DeviceReplay
+assert dist.get_backend() == "nccl" and not azdist._single()
+net = load_npz_checkpoint(os.path.join(%(root)r, "tests", "golden", "checkpoint_connect_four.npz"), [3, 6, 7], 7)
+gen = ExampleGenerator(net, "connect_four", torch.device("cuda:0"), n_playouts=12, n_slots=8, seed=77)
+games = gen.generate_examples(6)            # broadcast_net + all_gather_into_tensor of the device export, over RCCL
+rep = DeviceReplay("connect_four", max_games=16, device=0)
+n = gen.generate_into(rep, 4)               # ... and the device-to-device append of the gathered buffer
+u = rep.dedupe()
+t = azdist.all_reduce_sum(torch.tensor([1.5, 2.0], dtype=torch.float64), torch.device("cuda:0"))
+dist.barrier(device_ids=[0])
+json.dump({"games": len(games), "appended": n, "unique": int(u), "sum": t.tolist()}, open(os.environ["AZ_TEST_OUT"], "w"))
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_code_path_in_a_one_rank_group(tmp_path):
+    """The nccl (= RCCL) branch of every collective on the path - weight broadcast, all-gather of the packed device export,
+    all-reduce, barrier - executed for real on the one GPU of the test box: AZ_DIST_FORCE=1 makes a one-rank process group
+    run them instead of short-cutting.  (On an 8-GPU node the same calls carry 8 ranks over xGMI.)"""
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(_NCCL_WORKER % {"root": ROOT})
+    out_file = tmp_path / "out.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               AZ_DIST_FORCE="1", PYTHONDONTWRITEBYTECODE="1", AZ_TEST_OUT=str(out_file), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    got = json.load(open(out_file))
+    assert got == {"games": 6, "appended": 4, "unique": got["unique"], "sum": [1.5, 2.0]} and got["unique"] > 4
+
+
+def test_bench_multi_gpu_branch_runs_over_rccl_in_a_one_rank_group(tmp_path):
+    """bench.py's N > 1 branch (nccl init bound to the device, broadcast, barriers, device all-gather inside the timed region,
+    MAX / SUM all-reduces) with AZ_DIST_FORCE=1 and one rank."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29557", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               AZ_DIST_FORCE="1", PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--slots", "256",
+                          "--playouts", "50", "--blocks", "2", "--cpu-baseline", "off", "--ref-seconds", "0"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["allgather_ms"] is not None and line["allgather_ms"] > 0
