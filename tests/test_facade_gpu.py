@@ -3,8 +3,9 @@
 * play_game_self / AlphaZeroBot.step draw their randomness from numpy's global stream at the same two
   places as the reference (mcts.py:187, alphazerobot.py:84), so after np.random.seed(k) a façade game must equal
   the reference's game for the same seed and policy_fn — checked against the fixtures, bit for bit.
-* ExampleGenerator (bulk path: Philox on the device, fused fp16 net) is checked for format, determinism and —
-  statistically — against the oracle driven by the same network ("within stochastic-sampling tolerance").
+* ExampleGenerator (bulk path: Philox on the device, fused net in its default fp32-grade mode) is checked for format,
+  determinism and — statistically — against the oracle driven by the same network ("within stochastic-sampling tolerance");
+  the like-for-like search comparison of both fused precisions against fp32 is tests/test_precision_search_gpu.py.
 """
 import os
 
@@ -106,7 +107,7 @@ def test_example_generator_end_to_end_format_and_determinism():
 
 
 def test_bulk_self_play_statistics_match_the_oracle_with_the_same_net():
-    """First-move visit distribution and value targets, engine (Philox, fp16 fused net) vs the C oracle driven by
+    """First-move visit distribution and value targets, engine (Philox, fused net) vs the C oracle driven by
     the fp32 torch net: means over many games agree within sampling error (tolerance 0.04 on each pi component,
     i.e. ~4 standard errors of the 48-game oracle sample)."""
     from alphazero_openspiel_amd.examplegenerator import ExampleGenerator
