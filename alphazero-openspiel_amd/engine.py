@@ -369,7 +369,7 @@ def slot_groups(n_slots, k):
 
 
 def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_ticks=None, use_graph=False,
-                 on_tick=None, overlap=1, ticks_per_graph=8):
+                 on_tick=None, overlap=1, ticks_per_graph=16):
     """ExampleGenerator.run_games without processes: tick the engine until n_games are finished.
     Returns the final progress dict.
 

@@ -169,7 +169,7 @@ def main():
                     help="slot groups ticking on their own HIP streams (BASELINE configs[4]: overlapped PV-eval / tree-search "
                          "streams): a group's tree search and launch gaps run beside another group's forward")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--ticks-per-graph", type=int, default=8,
+    ap.add_argument("--ticks-per-graph", type=int, default=16,
                     help="ticks captured per HIP graph (one replay = that many ticks: fewer graph-boundary bubbles; measured 1 -> 4 -> 16: "
                          "2814 -> 2873 -> 2889 games/s on one box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
