@@ -20,12 +20,20 @@ ap.add_argument("--filters", type=int, default=50)
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--game", default="connect_four")
 ap.add_argument("--precision", default="f16", choices=["f16", "f32x"])
+ap.add_argument("--zero", action="store_true", help="zero weights and zero boards: the same instruction stream on all-zero MFMA operands "
+                                                    "(DVFS check: does the chip run the identical kernel faster when it draws less power?)")
 a = ap.parse_args()
 g = games.load_game(a.game)
 torch.manual_seed(0)
 net = Net(g.information_state_normalized_vector_shape(), g.num_distinct_actions(), n_blocks=a.blocks, n_filters=a.filters).eval()
+if a.zero:
+    with torch.no_grad():
+        for prm in net.parameters():
+            prm.zero_()
 fn = FusedNet(net, "cuda:0", max_boards=a.boards, precision=a.precision)
 obs = (torch.rand(a.boards, 4, g.rows, g.cols, device="cuda") > 0.5).float()  # random 0/1 planes
+if a.zero:
+    obs.zero_()
 pri = torch.empty(a.boards, g.num_distinct_actions(), device="cuda")
 val = torch.empty(a.boards, device="cuda")
 for _ in range(5):
