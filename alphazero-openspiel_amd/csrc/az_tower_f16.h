@@ -43,71 +43,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
         uint4 z = {0, 0, 0, 0};
         for (int i = lane * 16; i < region_b; i += 64 * 16) *(uint4 *)(lds + region + i) = z;
     }
-    // ---- per-lane tables: the NT*16 columns of this wave -----------------------------------------------------
-    int pos_addr[NT], grow[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        int b, y, x;
-        bool ok;
-        if (p.tpb) { // row-pair tile
-            b = nt / p.tpb;
-            y = 2 * (nt - b * p.tpb) + (l15 >> 3);
-            x = l15 & 7;
-            ok = x < p.W && y < p.H && b < p.bpw; // (a kernel with more tiles than the boards need masks the rest)
-        } else {
-            int n = nt * 16 + l15;
-            b = n / p.HW;
-            int pos = n - b * p.HW;
-            y = pos / p.W;
-            x = pos - y * p.W;
-            ok = b < p.bpw;
-        }
-        ok = ok && (board0 + b < p.n_boards);
-        int cell = b * p.cells + (y + 1) * p.rs + (x + 1);
-        pos_addr[nt] = region + ((ok || p.tpb) ? cell : p.zcell) * OCT_B; // row-pair padding lanes read their (finite) neighbours
-        grow[nt] = ok ? (board0 + b) * p.HW + y * p.W + x : -1;
-    }
-    int koff[AZ_NET_KSTEPS]; // byte offset (tap shift + octet plane) of this lane's k-group in each k-step
-#pragma unroll
-    for (int ks = 0; ks < AZ_NET_KSTEPS; ks++) {
-        int g = 4 * ks + q, tap, c8;
-        bool zero;
-        if (L15) {
-            tap = g / 6, c8 = g - tap * 6;
-            zero = g >= 54;
-        } else {
-            tap = g / 7, c8 = g - tap * 7;
-            zero = g == 63;
-        }
-        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        koff[ks] = zero ? 0 : (dy * p.rs + dx) * OCT_B + c8 * plane_b; // zero groups: zero weights, any finite data
-        if (RP1) koff[ks] += (int)lds_base + pos_addr[0];              // the full LDS address of tile 0's fragment
-    }
-    // L15: channels 48, 49 live in a COMPACT plane - 4 bytes per cell in the space of octet plane 6 - so that the 4-byte
-    // gather reads of the last k-step touch 16 consecutive dwords per 16 columns (at the octet planes' 16-byte cell stride
-    // they were 4-way bank conflicted: 17 % of the kernel's LDS cycles, profiles/r2_bench_default_pmc_summary.txt)
-    int p6_addr[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) p6_addr[nt] = region + 6 * plane_b + ((pos_addr[nt] - region) >> 2);
-    int ksp[4]; // the four taps of this lane's group in the last k-step
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int tap = 4 * q + i;
-        tap = tap > 8 ? 8 : tap; // (taps past the ninth carry zero weights)
-        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        ksp[i] = (dy * p.rs + dx) * 4;
-        if (RP1) ksp[i] += (int)lds_base + p6_addr[0];
-    }
-    // conv 0 reads the 4 input planes only (octet 0): K = 9 taps x 1 octet, packed as ONE 4-k-step chunk
-    // (group g < 9 = tap g of octet 0, groups 9..15 zero weights) instead of 16 k-steps that are 6/7 zeros.
-    int koff0[AZ_NET_K0STEPS];
-#pragma unroll
-    for (int ks = 0; ks < AZ_NET_K0STEPS; ks++) {
-        int g = 4 * ks + q;
-        int dy = g / 3 - 1, dx = g - (g / 3) * 3 - 1;
-        koff0[ks] = g < 9 ? (dy * p.rs + dx) * OCT_B : 0;
-        if (RP1) koff0[ks] += (int)lds_base + pos_addr[0];
-    }
+    // ---- per-lane tables: the NT*16 columns of this wave, the k-group offsets of every k-step (az_net_common.h) -----------
+    TowerTables<NT, RP1, L15> T;
+    T.init(p, region, plane_b, lds_base, board0, q, l15);
+    int (&pos_addr)[NT] = T.pos_addr, (&grow)[NT] = T.grow, (&p6_addr)[NT] = T.p6_addr;
+    int (&koff)[AZ_NET_KSTEPS] = T.koff, (&ksp)[4] = T.ksp, (&koff0)[AZ_NET_K0STEPS] = T.koff0;
 
     f32x4 acc[4][NT], xres[4][NT];
 #ifdef AZ_ABL_SKEW // (timing-only) waves 4..7 start AZ_ABL_SKEW x 64 cycles late

@@ -43,62 +43,10 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3_kernel(TowerParams p) {
         uint4 z = {0, 0, 0, 0};
         for (int i = lane * 16; i < 2 * lo_off; i += 64 * 16) *(uint4 *)(lds + region + i) = z;
     }
-    int pos_addr[NT], grow[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        int y, x;
-        bool ok;
-        if (p.tpb) {
-            y = 2 * nt + (l15 >> 3);
-            x = l15 & 7;
-            ok = x < p.W && y < p.H && nt < p.tpb;
-        } else {
-            int pos = nt * 16 + l15;
-            y = pos / p.W;
-            x = pos - y * p.W;
-            ok = pos < p.HW;
-        }
-        ok = ok && board0 < p.n_boards;
-        int cell = (y + 1) * p.rs + (x + 1);
-        pos_addr[nt] = region + ((ok || p.tpb) ? cell : p.zcell) * OCT_B;
-        grow[nt] = ok ? board0 * p.HW + y * p.W + x : -1;
-    }
-    int koff[AZ_NET_KSTEPS];
-#pragma unroll
-    for (int ks = 0; ks < AZ_NET_KSTEPS; ks++) {
-        int g = 4 * ks + q, tap, c8;
-        bool zero;
-        if (L15) {
-            tap = g / 6, c8 = g - tap * 6;
-            zero = g >= 54;
-        } else {
-            tap = g / 7, c8 = g - tap * 7;
-            zero = g == 63;
-        }
-        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        koff[ks] = zero ? 0 : (dy * p.rs + dx) * OCT_B + c8 * plane_b;
-        if (RP1) koff[ks] += (int)lds_base + pos_addr[0];
-    }
-    int p6_addr[NT]; // compact plane of channels 48, 49 (4 bytes per cell, see az_tower_kernel); its lo twin at + lo_off
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) p6_addr[nt] = region + 6 * plane_b + ((pos_addr[nt] - region) >> 2);
-    int ksp[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int tap = 4 * q + i;
-        tap = tap > 8 ? 8 : tap;
-        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        ksp[i] = (dy * p.rs + dx) * 4;
-        if (RP1) ksp[i] += (int)lds_base + p6_addr[0];
-    }
-    int koff0[AZ_NET_K0STEPS];
-#pragma unroll
-    for (int ks = 0; ks < AZ_NET_K0STEPS; ks++) {
-        int g = 4 * ks + q;
-        int dy = g / 3 - 1, dx = g - (g / 3) * 3 - 1;
-        koff0[ks] = g < 9 ? (dy * p.rs + dx) * OCT_B : 0;
-        if (RP1) koff0[ks] += (int)lds_base + pos_addr[0];
-    }
+    TowerTables<NT, RP1, L15> T; // per-lane address tables (az_net_common.h); one board per wave here
+    T.init(p, region, plane_b, lds_base, board0, q, l15);
+    int (&pos_addr)[NT] = T.pos_addr, (&grow)[NT] = T.grow, (&p6_addr)[NT] = T.p6_addr;
+    int (&koff)[AZ_NET_KSTEPS] = T.koff, (&ksp)[4] = T.ksp, (&koff0)[AZ_NET_K0STEPS] = T.koff0;
 
     // x -> (hi, lo): hi = fp16(x), lo = fp16((x - hi) * 2048)
     auto split4 = [&](const f32x4 &v, half4 &hi, half4 &lo) {
