@@ -129,7 +129,7 @@ template <bool X3, int HEAD_MT> __global__ __launch_bounds__(256) void az_head_l
     constexpr int FRAGS = CK * HEAD_OTG * NPART;         // KiB fragments per chunk: [part][ksl][o]
     constexpr int CHUNK_B = FRAGS * 1024;
     constexpr int PER = FRAGS / 4 + CK * NPART * HEAD_MT; // vector-memory operations one wave issues per chunk
-    static_assert(FRAGS % 4 == 0 && 2 * PER < 64, "pieces split evenly over the 4 waves; the counted waits fit vmcnt");
+    static_assert(FRAGS % 4 == 0 && (HEAD_RING - 2) * PER < 64, "pieces split evenly over the 4 waves; the counted waits fit vmcnt");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l15 = lane & 15;
     // XCD-aware tile order.  Workgroup L runs on XCD L % 8 (each XCD has its own L2): the column groups of one board tile get
     // CONSECUTIVE slots of ONE XCD, so the tower output of those boards comes in from the Infinity Cache / HBM once and is
@@ -204,9 +204,10 @@ template <bool X3, int HEAD_MT> __global__ __launch_bounds__(256) void az_head_l
             if (c < n_chunks) {
                 // chunk c has landed once at most the operations of the (up to RING - 2) younger chunks are outstanding
                 const int younger = n_chunks - 1 - c < HEAD_RING - 2 ? n_chunks - 1 - c : HEAD_RING - 2;
-                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                static_for<HEAD_RING - 1>([&](auto y_c) { // (a literal operand per possible count)
+                    constexpr int y = decltype(y_c)::value;
+                    if (younger == y) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(y * PER) : "memory");
+                });
                 // a BARE barrier: __syncthreads() carries a fence that drains vmcnt to 0 and with it the chunks in flight
                 __builtin_amdgcn_s_barrier(); // everybody's pieces of chunk c are in LDS, and the slot of chunk c - 1 is free again
                 asm volatile("" ::: "memory");
