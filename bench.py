@@ -138,8 +138,11 @@ def cpu_baseline(game_name, S, n_blocks, n_filters, weight_seed, quick=False, ch
                           "seconds": c1["seconds"]},
         # BASELINE.md section 2 (build container, 8 cores, pygames stub): the real reference's multi-process path reached
         # 0.106 games/s / 1.34 k sims/s at 400 sims (8 processes), 0.91 games/s at 25 sims (1 process, 5-block checkpoint)
-        "reference_calibration": {"where": "build container, 8 cores (BASELINE.md section 2)",
-                                  "reference_400sims_8proc_games_per_s": 0.106, "reference_25sims_1proc_games_per_s": 0.91},
+        "reference_calibration": {"where": "build container, 8 cores (BASELINE.md section 2; oracle/calibrate_reference.py)",
+                                  "reference_400sims_8proc_games_per_s": 0.106, "reference_25sims_1proc_games_per_s": 0.91,
+                                  # the REAL reference's in-process play_game_self (policy_fn = Net.predict, 1 thread, shipped
+                                  # checkpoint) against this restatement with the same network, plies per second:
+                                  "restatement_over_reference_per_ply": {"25_sims": 1.23, "400_sims": 1.00}},
     }
 
 
