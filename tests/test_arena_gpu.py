@@ -57,10 +57,10 @@ def test_shipped_checkpoints_beat_the_rollout_bot_as_the_reference_reports():
     s1, s2, prog = arena.play_tests(net, "breakthrough(rows=6,columns=6)", 64, "zero", "uct", opponent_sims=200, device="cuda:0",
                                     seed=1, n_playouts=100, c_puct=2.5)
     assert prog["error_flags"] == 0 and set(np.unique(np.concatenate([s1, s2]))) <= {-1.0, 1.0}
-    assert float((s1.sum() + s2.sum()) / 128) > 0.9          # tournament.py:19-22: ">99 %" of the games
+    assert float((s1.sum() + s2.sum()) / 128) > 0.95         # tournament.py:19-22: ">99 %" of the games (1024 / 1024 measured)
     net4 = _ckpt("connect_four", [3, 6, 7], 7)
     s1, s2, _ = arena.play_tests(net4, "connect_four", 64, "zero", "uct", opponent_sims=200, device="cuda:0", seed=2, n_playouts=100)
-    assert float((s1.sum() + s2.sum()) / 128) > 0.5
+    assert float((s1.sum() + s2.sum()) / 128) > 0.75         # (985 wins, 8 draws of 1024 measured)
     s1, s2, _ = arena.play_tests(net4, "connect_four", 128, "net", "random", device="cuda:0", seed=3)
     assert float((s1.sum() + s2.sum()) / 256) > 0.6          # the raw network alone beats random play
 
