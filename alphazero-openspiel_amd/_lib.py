@@ -10,7 +10,8 @@ LIB_PATH = os.environ.get("AZ_ENGINE_LIB") or os.path.join(HERE, "libaz_engine.s
 GAME_CONNECT_FOUR, GAME_BREAKTHROUGH = 0, 1
 BACKUPS = {"on-policy": 0, "soft-Z": 1, "A0C": 2, "off-policy": 3}
 RNG_PHILOX, RNG_INJECTED = 0, 1
-FAULTS = {1: "POOL_EXHAUSTED", 2: "PLY_OVERFLOW", 4: "NO_VISITS", 8: "BAD_PRIOR", 16: "ILLEGAL_ACTION"}
+FAULTS = {1: "POOL_EXHAUSTED", 2: "PLY_OVERFLOW", 4: "NO_VISITS", 8: "BAD_PRIOR", 16: "ILLEGAL_ACTION", 32: "VISIT_RANGE"}
+SELECT_PUCT, SELECT_UCT = 0, 1
 ACTION_NONE, ACTION_SEARCH_AGAIN = -1, -2
 ARENA_AGENTS = {None: 0, "zero": 1, "net": 2}
 OPPONENTS = {None: 0, "random": 1, "uct": 2, "external": 3}
@@ -25,7 +26,9 @@ class AzConfig(C.Structure):
                 ("c_puct", C.c_double), ("dirichlet_ratio", C.c_double), ("dirichlet_alpha", C.c_double),
                 ("temperature", C.c_double), ("seed", C.c_uint64),
                 ("arena_agent", C.c_int32), ("arena_opponent", C.c_int32), ("opponent_sims", C.c_int32),
-                ("arena_flip", C.c_int32), ("opponent_uct_c", C.c_double)]
+                ("arena_flip", C.c_int32), ("opponent_uct_c", C.c_double),
+                ("select_rule", C.c_int32), ("arena_probabilistic", C.c_int32),
+                ("num_probabilistic_actions", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class AzSizes(C.Structure):

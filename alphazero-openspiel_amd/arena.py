@@ -19,7 +19,8 @@ import torch
 
 from .engine import DeviceEvaluator, EngineError, SelfPlayEngine
 
-_ENGINE_KW = ("n_playouts", "c_puct", "temperature", "keep_search_tree")
+_ENGINE_KW = ("n_playouts", "c_puct", "temperature", "keep_search_tree", "use_puct", "use_probabilistic_actions",
+              "num_probabilistic_actions")
 
 
 def arena_engine(game, n_slots, n_games, agent, opponent, opponent_sims=0, device=0, seed=0, **kwargs):

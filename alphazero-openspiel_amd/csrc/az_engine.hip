@@ -330,6 +330,7 @@ __device__ uint32_t compact_subtree(const Pool &a, const Pool &b, uint32_t root,
 // Slot registers shared by the kernels
 struct SlotRegs {
     int gid, sims, half;
+    int rule; // AZ_SELECT_* of the slot's current tree (the reference's Node.use_puct, uniform within a tree)
     uint32_t root, alloc;
     AzState rs;
 };
@@ -340,6 +341,8 @@ __device__ __forceinline__ void slot_load(const Params &p, int g, SlotRegs &r) {
     r.rs.ply = rfl(p.ply[g]);
     r.sims = rfl(p.sims[g]);
     r.half = rfl(p.which[g]);
+    r.rule = r.half >> 1;
+    r.half &= 1;
     r.root = rflu(p.root[g]);
     r.alloc = rflu(p.alloc[g]);
 }
@@ -350,7 +353,7 @@ __device__ __forceinline__ void slot_store(const Params &p, int g, const SlotReg
     p.bb1[g] = r.rs.bb1;
     p.ply[g] = r.rs.ply;
     p.sims[g] = r.sims;
-    p.which[g] = r.half;
+    p.which[g] = r.half | (r.rule << 1);
     p.root[g] = r.root;
     p.alloc[g] = r.alloc;
 }
@@ -376,11 +379,16 @@ __device__ __forceinline__ void backup_path(const Pool &t, Path<NP> &path, int d
 }
 
 // mcts.update_root(action) (mcts.py:192-203) + the pool bookkeeping it implies here.
-// `sel` = index of the chosen child among the root's children, or -1 for "fresh tree".
-__device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, int lane, unsigned int &fault,
-                       unsigned long long &st_compact) {
+// `sel` = index of the chosen child among the root's children, or -1 when the action is not among them (leaf root).
+// `drop`: the tree is dropped whatever it holds (a new game, or keep_search_tree=False: alphazerobot.py:66-67).
+// `fresh_rule`: the select rule of a root created here.  The reference keeps it per Node (use_puct, inherited by children:
+// mcts.py:64): MCTS.__init__'s root is always PUCT (mcts.py:122), a leaf root replaced by update_root takes MCTS.use_puct
+// (mcts.py:199-200) - so the caller says which of the two the reference would have built at this point.
+__device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, bool drop, int fresh_rule, int lane,
+                       unsigned int &fault, unsigned long long &st_compact) {
     uint32_t c0 = rflu(t.nd[sr.root].C0);
-    if (sel < 0 || c0 == NONE32) { // root.is_leaf() or keep_search_tree=False: a new root Node
+    if (drop || sel < 0 || c0 == NONE32) {
+        sr.rule = fresh_rule;
         sr.root = 0;
         sr.alloc = 1;
         pool_init_root(t, lane);
@@ -425,6 +433,13 @@ __device__ __forceinline__ bool finish_game_take_next(const Params &p, int g, in
     sr.sims = 0;
     return true;
 }
+// Rule of the tree a game's first search runs on, when the agent is the first to move from p.start.  A bot that keeps its
+// tree calls update_root on its (leaf) constructor root before its first search when the history is long enough - self-play
+// bots with >= 1 move played (alphazerobot.py:57-59), the others with >= 2 (:62-64) - which installs MCTS.use_puct.
+__device__ __forceinline__ int start_rule(const Params &p) {
+    if (!p.keep_tree || p.manual_moves) return AZ_SELECT_PUCT;
+    return p.start.ply >= (p.arena_agent == AZ_ARENA_SELF_PLAY ? 1 : 2) ? p.select_rule : AZ_SELECT_PUCT;
+}
 // arena: the agent plays side gid & 1; is it the OPPONENT's turn in state s of game gid?
 __device__ __forceinline__ bool opponent_to_move(const Params &p, int gid, const AzState &s) {
     return p.arena_agent != AZ_ARENA_SELF_PLAY && ((s.ply ^ gid ^ p.arena_flip) & 1);
@@ -467,10 +482,11 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
             ph = PH_IDLE;
         } else if (term) {
             if (!finish_game_take_next(p, g, lane, sr, ret0, 0)) return;
-            reroot(p, g, sr, t, -1, lane, fault, st_compact);
+            reroot(p, g, sr, t, -1, true, start_rule(p), lane, fault, st_compact);
             ph = opponent_to_move(p, sr.gid, sr.rs) ? PH_OPPONENT : (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN);
-        } else {
-            reroot(p, g, sr, t, sel, lane, fault, st_compact);
+        } else { // a leaf root here = the agent's first step of the game: update_root runs only with >= 2 moves played
+            reroot(p, g, sr, t, sel, !p.keep_tree, (p.keep_tree && sr.rs.ply >= 2) ? p.select_rule : AZ_SELECT_PUCT, lane, fault,
+                   st_compact);
             ph = p.use_dirichlet ? PH_NEED_ROOT : PH_RUN;
         }
     }
@@ -558,8 +574,10 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         unsigned long long gt = __ballot(lane < nc && mycdf > u);
         int sel = gt ? __ffsll(gt) - 1 : nc - 1;
         while (sel > 0 && __shfl(cn, sel) == 0) sel--; // rounding corner: never pick an unvisited child
-        if (p.arena_agent == AZ_ARENA_ZERO) { // outside self-play the bot is greedy: np.argmax of the tempered visit fractions
-                                              // (alphazerobot.py:86-91) = the first most-visited child
+        if ((p.arena_agent == AZ_ARENA_ZERO && !p.arena_prob) || (p.arena_agent != AZ_ARENA_NET && sr.rs.ply >= p.n_prob_plies)) {
+            // outside self-play the bot is greedy unless use_probabilistic_actions, and every bot is once
+            // num_probabilistic_actions moves are played: np.argmax of the tempered visit fractions (alphazerobot.py:81-86)
+            // = the first most-visited child
             double mx = wave_max(lane < nc ? ap : -INFINITY);
             sel = __ffsll((unsigned long long)__ballot(lane < nc && ap == mx)) - 1;
         } else if (p.arena_agent == AZ_ARENA_NET) { // NeuralNetBot.step (alphazerobot.py:105-120): argmax of the masked,
@@ -590,9 +608,9 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         sr.sims = 0;
         if (term) {
             if (!finish_game_take_next(p, g, lane, sr, ret0, st_moves)) return;
-            reroot(p, g, sr, t, -1, lane, fault, st_compact);
+            reroot(p, g, sr, t, -1, true, start_rule(p), lane, fault, st_compact);
         } else {
-            reroot(p, g, sr, t, p.keep_tree ? sel : -1, lane, fault, st_compact);
+            reroot(p, g, sr, t, sel, !p.keep_tree, p.keep_tree ? p.select_rule : AZ_SELECT_PUCT, lane, fault, st_compact);
         }
         ph = opponent_to_move(p, sr.gid, sr.rs) ? PH_OPPONENT : (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN);
     }
@@ -803,12 +821,16 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
                 cc0 = c.C0;
                 cmeta = c.META;
                 cq = c.Q;
-                val = c.Q + ((p.c_puct * c.P) * sqrt((double)np_)) / (double)(cn + 1); // mcts.py:78
+                if (sr.rule == AZ_SELECT_PUCT)
+                    val = c.Q + ((p.c_puct * c.P) * sqrt((double)np_)) / (double)(cn + 1); // mcts.py:78
+                else // mcts.py:80; log(N_parent) from the host's table (N_parent >= 1 whenever a child has a visit)
+                    val = cn == 0 ? INFINITY : c.Q + (p.c_puct * c.P) * sqrt(p.log_table[np_ < p.log_n ? np_ : 0u] / (double)cn);
             }
             double mx = wave_max(val);
             unsigned long long eq = __ballot(val == mx);
             int best = eq ? __ffsll(eq) - 1 : 0; // first maximum in child order (mcts.py:50)
             if (!eq) fault |= AZ_FAULT_BAD_PRIOR;
+            if (sr.rule != AZ_SELECT_PUCT && np_ >= p.log_n) fault |= AZ_FAULT_VISIT_RANGE;
             st_children += (unsigned long long)nc;
             node = c0 + (uint32_t)best;
             np_ = (uint32_t)__builtin_amdgcn_readlane((int)cn, best);
@@ -1017,7 +1039,7 @@ __global__ __launch_bounds__(256) void az_update_root_kernel(Params p, const int
     float ret0 = 0.f;
     int term = az_apply<GAME>(sr.rs, p.geom, action, &ret0);
     sr.sims = 0;
-    reroot(p, g, sr, t, sel, lane, fault, st_compact);
+    reroot(p, g, sr, t, sel, !keep_subtree, keep_subtree ? p.select_rule : AZ_SELECT_PUCT, lane, fault, st_compact);
     fault = wave_or(fault);
     if (lane == 0) {
         slot_store(p, g, sr, (term || fault) ? PH_IDLE : (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN));
@@ -1038,7 +1060,8 @@ __global__ void az_reset_kernel(Params p) {
     p.bb1[g] = p.start.bb1;
     p.ply[g] = p.start.ply;
     p.sims[g] = 0;
-    p.which[g] = 0;
+    p.which[g] = (!p.keep_tree || p.manual_moves ? AZ_SELECT_PUCT
+                  : (p.start.ply >= (p.arena_agent == AZ_ARENA_SELF_PLAY ? 1 : 2) ? p.select_rule : AZ_SELECT_PUCT)) << 1; // start_rule
     p.root[g] = 0;
     p.alloc[g] = 1;
     p.depth[g] = 0;
@@ -1146,6 +1169,13 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
                        "rng_mode PHILOX, manual_moves 0)";
         return AZ_E_INVALID;
     }
+    if ((c.select_rule != AZ_SELECT_PUCT && c.select_rule != AZ_SELECT_UCT) || c.reserved0 != 0 ||
+        (c.arena_probabilistic != 0 && c.arena_probabilistic != 1) ||
+        (c.arena_probabilistic && c.arena_agent != AZ_ARENA_ZERO)) {
+        g_create_err = "select_rule must be AZ_SELECT_PUCT or AZ_SELECT_UCT; arena_probabilistic 0/1 (AZ_ARENA_ZERO only); "
+                       "reserved0 must be 0";
+        return AZ_E_INVALID;
+    }
     if (!c.use_dirichlet && c.n_playouts < 2 && c.arena_agent != AZ_ARENA_NET) {
         g_create_err = "n_playouts must be >= 2 without root Dirichlet expansion (mcts.py:162 divides by zero)";
         return AZ_E_INVALID;
@@ -1251,10 +1281,22 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     DA(p.next_game, 1); DA(p.games_done, 1); DA(p.faults, 1);
     if (c.arena_agent != AZ_ARENA_SELF_PLAY) DA(p.opp_action, G);
     double *d_log = nullptr;
+    // log(n) table: the UCT opponent's explore counts stay <= opponent_sims; an AZ_SELECT_UCT tree's root gains n_playouts
+    // visits per search, one search per ply (+ slack for MCTS.search called again at the same root)
+    size_t log_n = 0;
     if (p.uct_cap) {
         DA(p.uct_N, G * p.uct_cap); DA(p.uct_C0, G * p.uct_cap); DA(p.uct_META, G * p.uct_cap); DA(p.uct_W, G * p.uct_cap);
-        DA(d_log, (size_t)c.opponent_sims + 2);
+        log_n = (size_t)c.opponent_sims + 2;
     }
+    if (c.select_rule == AZ_SELECT_UCT) {
+        size_t need = (size_t)c.n_playouts * ((size_t)p.max_plies + 2) + 2;
+        if (need > log_n) log_n = need;
+    }
+    if (log_n) DA(d_log, log_n);
+    p.log_n = (uint32_t)log_n;
+    p.select_rule = c.select_rule;
+    p.arena_prob = c.arena_probabilistic;
+    p.n_prob_plies = c.num_probabilistic_actions > 0 ? c.num_probabilistic_actions : (c.num_probabilistic_actions < 0 ? 0 : 1000); // alphazerobot.py:36
     DA(p.rec_len, (size_t)c.max_games); DA(p.rec_ret0, (size_t)c.max_games);
     DA(p.rec_states, plies * 2); DA(p.rec_move, plies); DA(p.rec_nchild, plies);
     DA(p.rec_child_action, plies * p.maxc); DA(p.rec_child_visits, plies * p.maxc); DA(p.rec_value, plies);
@@ -1267,7 +1309,7 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     (void)hipMemset(p.phase, 0, G * sizeof(int));
     (void)hipMemset(p.path, 0, G * p.pstride * sizeof(uint32_t));
     if (d_log) { // log(n) from the host's libm: the UCT values then agree bit for bit with the CPU restatement
-        std::vector<double> lt((size_t)c.opponent_sims + 2, 0.0);
+        std::vector<double> lt(log_n, 0.0);
         for (size_t i = 1; i < lt.size(); i++) lt[i] = log((double)i);
         (void)hipMemcpy(d_log, lt.data(), lt.size() * sizeof(double), hipMemcpyHostToDevice);
         p.log_table = d_log;
@@ -1669,6 +1711,7 @@ extern "C" int az_engine_read_root(az_engine *e, int32_t slot, int64_t *root_n, 
     int half = 0;
     uint32_t root = 0, n = 0, c0 = 0, meta = 0;
     HIPCHK(e, hipMemcpy(&half, e->p.which + slot, sizeof half, hipMemcpyDeviceToHost));
+    half &= 1; // bit 1 = the tree's select rule
     HIPCHK(e, hipMemcpy(&root, e->p.root + slot, sizeof root, hipMemcpyDeviceToHost));
     size_t base = ((size_t)slot * 2 + half) * e->p.cap;
     double q = 0;
@@ -1704,6 +1747,7 @@ extern "C" int64_t az_engine_read_tree(az_engine *e, int32_t slot, int64_t max_n
     int half = 0;
     uint32_t root = 0, alloc = 0;
     HIPCHK(e, hipMemcpy(&half, e->p.which + slot, sizeof half, hipMemcpyDeviceToHost));
+    half &= 1; // bit 1 = the tree's select rule
     HIPCHK(e, hipMemcpy(&root, e->p.root + slot, sizeof root, hipMemcpyDeviceToHost));
     HIPCHK(e, hipMemcpy(&alloc, e->p.alloc + slot, sizeof alloc, hipMemcpyDeviceToHost));
     if (alloc > e->p.cap || root >= alloc) {

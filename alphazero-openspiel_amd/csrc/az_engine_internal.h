@@ -63,7 +63,10 @@ struct Params {
     uint32_t uct_cap;          // UCT opponent: nodes per slot
     uint32_t *uct_N, *uct_C0, *uct_META; // [G][uct_cap] explore_count, first child, action | n_children << 16
     double *uct_W;             // [G][uct_cap] total_reward, seen by the player who moved into the node
-    const double *log_table;   // [opp_sims + 2] log(n) computed on the host (glibc), so that host and device agree bit for bit
+    const double *log_table;   // [log_n] log(n) computed on the host (glibc), so that host and device agree bit for bit
+    uint32_t log_n;
+    int arena_prob, n_prob_plies; // use_probabilistic_actions outside self-play; num_probabilistic_actions (alphazerobot.py:34-36)
+    int select_rule;           // AZ_SELECT_*: rule of the trees update_root starts from a leaf root (mcts.py:199-200)
     // records
     int *rec_len;
     float *rec_ret0;

@@ -36,7 +36,8 @@ class SelfPlayEngine:
     def __init__(self, game_name, n_slots, n_playouts=100, c_puct=2.5, temperature=1.0, dirichlet_ratio=0.25,
                  use_dirichlet=True, keep_search_tree=True, backup="on-policy", max_games=None, device=0,
                  rng="philox", seed=0, nodes_per_slot=0, max_sims_per_tick=0, chain_window_us=0, manual_moves=False,
-                 dirichlet_alpha=0.3, arena_agent=None, opponent=None, opponent_sims=0, opponent_uct_c=1.0, arena_flip=False):
+                 dirichlet_alpha=0.3, arena_agent=None, opponent=None, opponent_sims=0, opponent_uct_c=1.0, arena_flip=False,
+                 use_puct=True, use_probabilistic_actions=False, num_probabilistic_actions=1000):
         self.lib = _lib.load()
         self.game = Game(game_name) if isinstance(game_name, str) else game_name
         self.device_index = _device_index(device)
@@ -69,6 +70,11 @@ class SelfPlayEngine:
         cfg.opponent_sims = int(opponent_sims)
         cfg.opponent_uct_c = float(opponent_uct_c)
         cfg.arena_flip = int(bool(arena_flip))
+        # MCTS(use_puct=False) (mcts.py:80,199-200): the rule of trees that update_root starts from a leaf root
+        cfg.select_rule = _lib.SELECT_PUCT if use_puct else _lib.SELECT_UCT
+        # alphazerobot.py:34-36,81-86: an arena "zero" agent samples its moves (self-play always does), for the first n plies
+        cfg.arena_probabilistic = int(bool(use_probabilistic_actions) and arena_agent == "zero")
+        cfg.num_probabilistic_actions = int(num_probabilistic_actions) if int(num_probabilistic_actions) > 0 else -1
         self.cfg = cfg
         self.backup = backup
         self._h = C.c_void_p()

@@ -18,7 +18,7 @@ from .games import Game
 from . import distributed as azdist
 
 _ENGINE_KW = ("n_playouts", "c_puct", "temperature", "dirichlet_ratio", "use_dirichlet", "keep_search_tree",
-              "backup")
+              "backup", "use_puct", "num_probabilistic_actions")
 
 
 class ExampleGenerator:
@@ -26,8 +26,6 @@ class ExampleGenerator:
         self.net2 = copy.deepcopy(kwargs["net2"]) if kwargs.get("net2") is not None else None  # examplegenerator.py:88-90
         self.is_test = bool(kwargs.get("is_test", False))
         self.generate_statistics = bool(kwargs.get("generate_statistics", False))
-        if self.generate_statistics:
-            raise NotImplementedError("generate_statistics deep-copies search trees per move (game_utils.py:30-31): not built")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise EngineError("ExampleGenerator needs a HIP device: self-play runs in HIP kernels, there is no "
@@ -134,8 +132,21 @@ class ExampleGenerator:
         if world > 1:
             self.net = self.net.to(self.device)
             azdist.broadcast_net(self.net, src=0)
-        kw = {k: self.kwargs[k] for k in ("n_playouts", "c_puct", "temperature") if k in self.kwargs}
-        if name == "test_zero_vs_zero":  # two networks, each with its settings (game_utils.py:120-145; net2 defaults to net)
+        kw = {k: self.kwargs[k] for k in ("n_playouts", "c_puct", "temperature", "keep_search_tree", "use_puct",
+                                          "use_probabilistic_actions", "num_probabilistic_actions") if k in self.kwargs}
+        statistics = [None] * n_local  # the pairings against bots return no statistics (game_utils.py:65,83)
+        if name == "test_zero_vs_zero" and self.generate_statistics:
+            # both search trees after every move (game_utils.py:29-31): the reference's own per-game loop over façade bots,
+            # one device search per step - an inspection mode (tournament.py:39-52 plays one test per pairing with it)
+            from .game_utils import test_zero_vs_zero
+            net1 = self.net.to(self.device).eval()
+            net2 = (self.net2 if self.net2 is not None else self.net).to(self.device).eval()
+            out = [test_zero_vs_zero(net1, None, self.game_name, policy_fn2=net2, generate_statistics=True,
+                                     settings1=self.kwargs.get("settings1", kw), settings2=self.kwargs.get("settings2", kw))
+                   for _ in range(n_local)]
+            s1, s2 = np.array([o[0] for o in out], dtype=np.float64), np.array([o[1] for o in out], dtype=np.float64)
+            statistics = [o[2] for o in out]
+        elif name == "test_zero_vs_zero":  # two networks, each with its settings (game_utils.py:120-145; net2 defaults to net)
             if world > 1 and self.net2 is not None:
                 self.net2 = self.net2.to(self.device)
                 azdist.broadcast_net(self.net2, src=0)
@@ -149,7 +160,10 @@ class ExampleGenerator:
         self._generation += 1
         total = torch.tensor([float(s1.sum() + s2.sum()), float(2 * n_local)], dtype=torch.float64)
         total = azdist.all_reduce_sum(total, self.device)
-        return float(total[0] / total[1])
+        avg_reward = float(total[0] / total[1])
+        if self.generate_statistics:  # examplegenerator.py:192-193 (this rank's tests)
+            return avg_reward, statistics
+        return avg_reward
 
     def _play_tests(self, arena, n_local, pairing, n_playouts_mcts, rank, kw):
         return arena.play_tests(

@@ -27,6 +27,24 @@ def _a0gb_value(root):
     return value * mult
 
 
+def play_game(game, player1, player2, generate_statistics=False):
+    """One game between two step()-bots, player1 moving first -> returns()[0]; with generate_statistics also
+    {"player1": [{"root": Node}, ...], "player2": [...]}: both bots' search-tree roots after every move
+    (game_utils.py:16-35).  Host loop over façade bots (one engine slot each) - the batched arena is the fast path."""
+    statistics = {"player1": [], "player2": []}
+    state = game.new_initial_state()
+    while not state.is_terminal():
+        mover = player1 if len(state.history()) % 2 == 0 else player2
+        _, action = mover.step(state)
+        state.apply_action(int(action))
+        if generate_statistics:  # MCTS.root is a fresh host snapshot of the device tree: no deepcopy needed
+            statistics["player1"].append({"root": player1.mcts.root})
+            statistics["player2"].append({"root": player2.mcts.root})
+    if generate_statistics:
+        return state.returns()[0], statistics
+    return state.returns()[0]
+
+
 def play_game_self(policy_fn, game_name, **kwargs):
     game = load_game(game_name)
     state = game.new_initial_state()
@@ -88,9 +106,23 @@ def test_net_vs_random(policy_fn, game_name, **kwargs):
 def test_zero_vs_zero(policy_fn, max_search_nodes, game_name, policy_fn2=None, generate_statistics=False, **kwargs):
     """Two AlphaZeroBots (root noise on) with their own networks and `settings1` / `settings2`, each once as first player
     -> (score1, score2, statistics) from the first network's point of view (game_utils.py:120-145).  `max_search_nodes` is
-    unused, as in the reference.  generate_statistics (deep copies of both search trees after every move) is not built."""
+    unused, as in the reference.  With generate_statistics the two games run through `play_game` on façade bots (the
+    reference's own loop, one device search per step) and `statistics` = {"game1": {...}, "game2": {...}} holds both
+    players' tree roots after every move; without it the pair runs on the batched device arena."""
     if generate_statistics:
-        raise NotImplementedError("generate_statistics is not built")
+        game = load_game(game_name)
+        fn2 = policy_fn2 if policy_fn2 else policy_fn
+        settings1, settings2 = dict(kwargs.get("settings1") or {}), dict(kwargs.get("settings2") or {})
+        statistics = {}
+        bot1 = AlphaZeroBot(game, 0, policy_fn, use_dirichlet=True, **settings1)
+        bot2 = AlphaZeroBot(game, 1, fn2, use_dirichlet=True, **settings2)
+        score1, statistics["game1"] = play_game(game, bot1, bot2, generate_statistics=True)
+        bot1 = AlphaZeroBot(game, 1, policy_fn, use_dirichlet=True, **settings1)
+        bot2 = AlphaZeroBot(game, 0, fn2, use_dirichlet=True, **settings2)
+        score2, st2 = play_game(game, bot2, bot1, generate_statistics=True)
+        st2["player1"], st2["player2"] = st2["player2"], st2["player1"]  # keyed by network, not by seat
+        statistics["game2"] = st2
+        return score1, -score2, statistics
     from . import arena
     s1, s2, _ = arena.play_zero_vs_zero(policy_fn, policy_fn2, game_name, 1, settings1=kwargs.get("settings1"),
                                         settings2=kwargs.get("settings2"))

@@ -64,9 +64,6 @@ def _as_module(policy_fn):
 class MCTS:
     def __init__(self, policy_fn, num_distinct_actions, c_puct=2.5, n_playouts=100, use_dirichlet=True,
                  dirichlet_ratio=0.25, use_puct=True, **kwargs):
-        if not use_puct:
-            raise NotImplementedError("only the PUCT rule (mcts.py:78) is built; the UCT variant (mcts.py:80) is "
-                                      "outside the self-play path")
         self.num_distinct_actions = num_distinct_actions
         self.c_puct, self.n_playouts = c_puct, n_playouts
         self.use_dirichlet, self.dirichlet_ratio, self.use_puct = use_dirichlet, dirichlet_ratio, use_puct
@@ -74,6 +71,9 @@ class MCTS:
         self.device = kwargs.get("device", None)
         self._engine = None
         self._history = None  # action history of the engine's root state
+        # use_puct=False only governs trees whose root update_root() created from a LEAF root (mcts.py:199-200; the
+        # constructor's root is always PUCT, mcts.py:122).  Set when update_root() met a leaf root the engine does not hold.
+        self._leaf_update = False
         self._io = None
         self._evaluator = None
         self.n_evals = 0
@@ -93,7 +93,7 @@ class MCTS:
         self._engine = SelfPlayEngine(game, 1, n_playouts=self.n_playouts, c_puct=self.c_puct,
                                       use_dirichlet=self.use_dirichlet, dirichlet_ratio=self.dirichlet_ratio,
                                       keep_search_tree=True, manual_moves=True, rng="injected", device=dev,
-                                      max_games=1, max_sims_per_tick=max(32, self.n_playouts))
+                                      use_puct=self.use_puct, max_games=1, max_sims_per_tick=max(32, self.n_playouts))
         self._io = self._engine.alloc_io()
         mod = _as_module(self.policy_fn)
         self._evaluator = DeviceEvaluator(mod, self._engine.device) if mod is not None else None
@@ -107,8 +107,15 @@ class MCTS:
     def _sync_root(self, state):
         hist = [int(a) for a in state.history()]
         if self._history is None or hist[:len(self._history)] != self._history or len(hist) > len(self._history) + 2:
-            self._restart(hist)
+            if self._leaf_update and hist:  # replay the last move through the engine's update_root: leaf root -> new root
+                self._restart(hist[:-1])    # with the configured select rule
+                self._engine.update_root([hist[-1]], keep_subtree=True)
+                self._history.append(hist[-1])
+            else:
+                self._restart(hist)
+            self._leaf_update = False
             return
+        self._leaf_update = False
         for a in hist[len(self._history):]:
             self.update_root(a)
 
@@ -173,17 +180,28 @@ class MCTS:
         return [float(v) / total for v in visits]
 
     def update_root(self, action):
-        if self._engine is None:
+        if self._engine is None:  # the constructor's root is a leaf: mcts.py:199-200 replaces it
+            self._leaf_update = True
             return
         e = self._engine
         info = e.read_slot(0)
         if info["phase"] == 0:  # idle slot (terminal position reached): restart lazily on the next search
             self._history = None
+            self._leaf_update = True  # a terminal node is never expanded: the reference replaces that leaf root too
             return
         e.update_root([int(action)], keep_subtree=True)
         self._history.append(int(action))
         if e.read_slot(0)["phase"] == 0:
             self._history = None
+
+    def random_rollout(self, state):
+        """A policy_fn substitute (mcts.py:205-223): flat priors of 1 and the outcome of one uniformly random play-out, seen by
+        the player to move in `state`.  Host side, numpy's global stream, like the reference's."""
+        sim = state.clone()
+        me = sim.current_player()
+        while not sim.is_terminal():
+            sim.apply_action(int(np.random.choice(sim.legal_actions())))
+        return np.ones(self.num_distinct_actions), sim.player_return(me)
 
     @property
     def root(self):

@@ -53,6 +53,7 @@ extern "C" {
 #define AZ_FAULT_NO_VISITS 4u      /* root has no visited child at move time (S too small) */
 #define AZ_FAULT_BAD_PRIOR 8u      /* NaN prior/value fed to advance */
 #define AZ_FAULT_ILLEGAL_ACTION 16u /* az_engine_update_root was given an action that is illegal in the slot's root state */
+#define AZ_FAULT_VISIT_RANGE 32u    /* AZ_SELECT_UCT: a node's visit count left the log(N) table (N > n_playouts * (max_plies + 2)) */
 
 #define AZ_ACTION_NONE (-1)         /* az_engine_update_root: leave the slot alone */
 #define AZ_ACTION_SEARCH_AGAIN (-2) /* az_engine_update_root: search the same root again (MCTS.search called twice, mcts.py:164-180) */
@@ -97,7 +98,22 @@ typedef struct az_config {
     int32_t opponent_sims;  /* AZ_OPPONENT_UCT: max_search_nodes of mcts.MCTSBot (game_utils.py:74-75) */
     int32_t arena_flip;     /* 1: the agent takes the OTHER side, (i & 1) ^ 1 - the second network of a two-engine pairing */
     double opponent_uct_c;  /* AZ_OPPONENT_UCT: uct_c (1 in the reference's calls) */
+    /* MCTS(use_puct=...) (mcts.py:101,120): the rule of the trees that update_root STARTS when it finds a leaf root
+     * (mcts.py:199-200).  The reference keeps the rule per Node, children inherit their parent's (mcts.py:64), and
+     * MCTS.__init__ always builds a PUCT root (mcts.py:122): so a tree is PUCT unless it grew from a root created by
+     * update_root on a leaf - reproduced here as one rule bit per slot tree.  0 (AZ_SELECT_PUCT) = use_puct=True. */
+    int32_t select_rule; /* AZ_SELECT_* */
+    /* AlphaZeroBot(use_probabilistic_actions=True) outside self-play (alphazerobot.py:34,83-84; tournament.py:35-36):
+     * the AZ_ARENA_ZERO agent samples its move from the tempered visit distribution instead of taking the argmax. */
+    int32_t arena_probabilistic;
+    /* num_probabilistic_actions (alphazerobot.py:36,81-85): a sampling agent (self-play, or arena_probabilistic) samples
+     * only while fewer than this many moves have been played, then plays the argmax.  0 = the reference's default, 1000; < 0 = never sample. */
+    int32_t num_probabilistic_actions;
+    int32_t reserved0; /* 0 */
 } az_config;
+
+#define AZ_SELECT_PUCT 0 /* Q + c_puct * P * sqrt(N_parent) / (N + 1)                         mcts.py:78 */
+#define AZ_SELECT_UCT 1  /* inf if N == 0 else Q + c_puct * P * sqrt(log(N_parent) / N)       mcts.py:80 */
 
 #define AZ_ARENA_SELF_PLAY 0
 #define AZ_ARENA_ZERO 1 /* AlphaZeroBot outside self-play: search, then the most visited move (alphazerobot.py:86-91), tree kept

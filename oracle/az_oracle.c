@@ -527,6 +527,7 @@ static void rng_dirichlet(orc_rng *r, double alpha, int n, double *out) {
 typedef struct {
     orc_mcts *mcts;
     int32_t num_actions, self_play, keep_search_tree, use_probabilistic_actions;
+    int32_t num_probabilistic_actions; /* alphazerobot.py:36 */
     double temperature;
     /* ctor args kept to rebuild the tree when keep_search_tree is False */
     double c_puct, dirichlet_ratio;
@@ -543,6 +544,7 @@ orc_bot *orc_bot_new(int num_actions, int self_play, int keep_search_tree, doubl
     b->self_play = self_play;
     b->keep_search_tree = keep_search_tree;
     b->use_probabilistic_actions = self_play; /* alphazerobot.py:32 */
+    b->num_probabilistic_actions = 1000;      /* alphazerobot.py:36 */
     b->temperature = temperature;
     b->c_puct = c_puct;
     b->dirichlet_ratio = dirichlet_ratio;
@@ -598,7 +600,7 @@ int orc_bot_step(orc_bot *b, const orc_state *state, const double *eta, double u
     }
     for (int a = 0; a < A; a++) ap[a] = ap[a] / tot;
     int action;
-    if (b->use_probabilistic_actions && state->nhist < 1000)
+    if (b->use_probabilistic_actions && state->nhist < b->num_probabilistic_actions)
         action = np_choice(ap, A, u);
     else { /* np.argmax: first maximum */
         action = 0;
@@ -621,7 +623,7 @@ typedef struct {
     double c_puct, dirichlet_ratio, temperature;
     uint64_t seed; /* used only when etas/us are NULL */
     int32_t max_moves; /* >0: stop after this many moves (bounded timing sample); 0 = play to the end */
-    int32_t reserved;
+    int32_t num_probabilistic_actions; /* alphazerobot.py:36; 0 = the default 1000, < 0 = never sample */
 } orc_selfplay_cfg;
 
 /* off-policy / A0GB target (game_utils.py:182-194) */
@@ -668,6 +670,7 @@ int orc_play_game_self(const orc_selfplay_cfg *cfg, orc_policy_fn fn, void *user
     int ncell4 = 4 * cfg->rows * cfg->cols;
     orc_bot *bot = orc_bot_new(A, 1, cfg->keep_search_tree, cfg->temperature, cfg->c_puct, cfg->n_playouts,
                                cfg->use_dirichlet, cfg->dirichlet_ratio, cfg->use_puct, fn, user);
+    if (cfg->num_probabilistic_actions) bot->num_probabilistic_actions = cfg->num_probabilistic_actions > 0 ? cfg->num_probabilistic_actions : 0;
     orc_rng rng = {cfg->seed};
     double eta_buf[ORC_MAX_CELLS * 3];
     int32_t legal[ORC_MAX_CELLS * 3];
@@ -866,7 +869,8 @@ typedef struct {
     double c_puct, temperature, opponent_uct_c;
     uint64_t seed;
     int32_t game_id; /* the agent plays side game_id & 1; the Philox stream is keyed by it */
-    int32_t reserved;
+    int32_t sample_plies; /* > 0: AlphaZeroBot(use_probabilistic_actions=True, num_probabilistic_actions=sample_plies)
+                             (alphazerobot.py:34-36,81-86); 0: the greedy bot of the test_* pairings */
 } orc_arena_cfg;
 
 /* game_utils.play_game (game_utils.py:16-35) between the agent (AlphaZeroBot outside self-play, alphazerobot.py:42-93,
@@ -879,13 +883,19 @@ int orc_play_arena_game(const orc_arena_cfg *cfg, orc_policy_fn fn, void *user, 
     orc_bot *bot = cfg->agent == ORC_ARENA_ZERO
                        ? orc_bot_new(A, 0, cfg->keep_search_tree, cfg->temperature, cfg->c_puct, cfg->n_playouts, 0, 0.25, 1, fn, user)
                        : NULL;
+    if (bot && cfg->sample_plies > 0) {
+        bot->use_probabilistic_actions = 1;
+        bot->num_probabilistic_actions = cfg->sample_plies;
+    }
     double *pol = (double *)malloc(sizeof(double) * (size_t)A), *board = (double *)malloc(sizeof(double) * 4 * ORC_MAX_CELLS);
     int n = 0;
     while (!s.terminal) {
         int action;
         if ((s.nhist & 1) == (cfg->game_id & 1)) { /* the agent's turn */
             if (cfg->agent == ORC_ARENA_ZERO) {
-                action = orc_bot_step(bot, &s, NULL, 0.0, pol);
+                orc_philox ru; /* the uniform behind np.random.choice: the engine's move stream (purpose 1) */
+                philox_init(&ru, cfg->seed, (uint32_t)cfg->game_id, (uint32_t)s.nhist, 1u, 0u);
+                action = orc_bot_step(bot, &s, NULL, philox_u01(&ru), pol);
             } else {
                 action = net_bot_step(fn, user, &s, A, pol, board);
             }

@@ -24,14 +24,14 @@ class SelfplayCfg(C.Structure):
                 ("n_playouts", C.c_int32), ("use_dirichlet", C.c_int32), ("use_puct", C.c_int32),
                 ("keep_search_tree", C.c_int32), ("backup", C.c_int32),
                 ("c_puct", C.c_double), ("dirichlet_ratio", C.c_double), ("temperature", C.c_double),
-                ("seed", C.c_uint64), ("max_moves", C.c_int32), ("reserved", C.c_int32)]
+                ("seed", C.c_uint64), ("max_moves", C.c_int32), ("num_probabilistic_actions", C.c_int32)]
 
 
 class ArenaCfg(C.Structure):
     _fields_ = [("game", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("n_playouts", C.c_int32),
                 ("keep_search_tree", C.c_int32), ("agent", C.c_int32), ("opponent", C.c_int32), ("opponent_sims", C.c_int32),
                 ("c_puct", C.c_double), ("temperature", C.c_double), ("opponent_uct_c", C.c_double), ("seed", C.c_uint64),
-                ("game_id", C.c_int32), ("reserved", C.c_int32)]
+                ("game_id", C.c_int32), ("sample_plies", C.c_int32)]
 
 
 class DuelCfg(C.Structure):
@@ -258,7 +258,7 @@ def max_plies(game, rows, cols):
 
 def play_game_self(py_policy, game_name, n_playouts=100, c_puct=2.5, temperature=1.0, dirichlet_ratio=0.25,
                    use_dirichlet=True, use_puct=True, keep_search_tree=True, backup="on-policy",
-                   etas=None, us=None, seed=0, max_moves=0, **_ignored):
+                   etas=None, us=None, seed=0, max_moves=0, num_probabilistic_actions=1000, **_ignored):
     """game_utils.py:148-206 through the C restatement.
 
     Returns dict(examples=[[key, board(4,H,W) f64, pi list[A], value]], actions, root_cN, ret0, counters)."""
@@ -267,7 +267,8 @@ def play_game_self(py_policy, game_name, n_playouts=100, c_puct=2.5, temperature
     A = L.orc_num_actions(g, r, c)
     mp = max_plies(g, r, c)
     cfg = SelfplayCfg(g, r, c, n_playouts, int(use_dirichlet), int(use_puct), int(keep_search_tree),
-                      BACKUPS[backup], c_puct, dirichlet_ratio, temperature, seed, int(max_moves), 0)
+                      BACKUPS[backup], c_puct, dirichlet_ratio, temperature, seed, int(max_moves),
+                      int(num_probabilistic_actions) if int(num_probabilistic_actions) > 0 else -1)
     cb = wrap_policy(py_policy, A, 4 * r * c)
     stride = 3 * r * c
     eta_arr = None
@@ -306,7 +307,8 @@ def play_game_self(py_policy, game_name, n_playouts=100, c_puct=2.5, temperature
 
 
 def play_arena_game(py_policy, game_name, game_id, agent="zero", opponent="uct", opponent_sims=0, n_playouts=100, c_puct=2.5,
-                    temperature=1.0, keep_search_tree=True, opponent_uct_c=1.0, seed=0):
+                    temperature=1.0, keep_search_tree=True, opponent_uct_c=1.0, seed=0, use_probabilistic_actions=False,
+                    num_probabilistic_actions=1000):
     """game_utils.play_game between the network-driven agent (side game_id & 1) and an opponent bot, through the C
     restatement.  Returns dict(actions, ret0)."""
     L = lib()
@@ -315,7 +317,8 @@ def play_arena_game(py_policy, game_name, game_id, agent="zero", opponent="uct",
     if agent == "net":
         n_playouts, keep_search_tree = 1, False
     cfg = ArenaCfg(g, r, c, n_playouts, int(keep_search_tree), ARENA_AGENTS[agent], OPPONENTS[opponent], int(opponent_sims),
-                   c_puct, temperature, opponent_uct_c, seed, int(game_id), 0)
+                   c_puct, temperature, opponent_uct_c, seed, int(game_id),
+                   max(0, int(num_probabilistic_actions)) if use_probabilistic_actions and agent == "zero" else 0)
     cb = wrap_policy(py_policy, A, 4 * r * c)
     mp = max_plies(g, r, c)
     actions = np.zeros(mp, dtype=np.int32)

@@ -159,9 +159,77 @@ def gen_mcts_traces(ref):
     return cases
 
 
-def gen_selfplay(ref):
-    games = []
+def gen_mcts_traces_uct(ref):
+    """MCTS(use_puct=False) (mcts.py:80).  The constructor's root is always a PUCT node (mcts.py:122) and children inherit
+    their parent's rule (mcts.py:64), so the UCT formula only ever runs in a tree whose root update_root() created from a
+    LEAF root (mcts.py:199-200).  Each case: optional update_root(prefix[-1]) on the untouched tree, then `n_searches`
+    rounds of [expand_root_dirichlet], S playouts (traced), update_root(most visited move)."""
+    cases = []
     specs = [
+        # (game, prefix, n_playouts, use_dirichlet, c_puct, salt, seed, leaf_update, n_searches)
+        ("connect_four", [3], 96, False, 2.5, 31, None, True, 2),
+        ("connect_four", [3, 3, 2, 4, 1], 80, True, 1.0, 32, 21, True, 2),
+        ("connect_four", [3, 2, 3, 2, 3, 2], 64, False, 2.5, 33, None, True, 1),  # win-in-one: terminal hits
+        ("connect_four", [2], 64, False, 2.5, 34, None, False, 2),  # no update_root before the search: stays PUCT
+        ("breakthrough(rows=6,columns=6)", [], 96, False, 2.5, 35, None, True, 2),
+        ("breakthrough(rows=8,columns=8)", [], 48, True, 2.5, 36, 22, True, 1),
+    ]
+    for game_name, prefix, S, use_dir, c_puct, salt, seed, leaf_update, n_searches in specs:
+        game = pygames.load_game(game_name)
+        A = game.num_distinct_actions()
+        shape = game.information_state_normalized_vector_shape()
+        state = game.new_initial_state()
+        for a in prefix:
+            state.apply_action(a)
+        if game_name.startswith("breakthrough") and not prefix:
+            rng = np.random.RandomState(salt)
+            for _ in range(9):
+                la = state.legal_actions()
+                state.apply_action(la[rng.randint(len(la))])
+            prefix = state.history()
+        pf = fakepolicy.make_policy_fn(ref.network.state_to_board, shape, A, salt)
+        tree = ref.mcts.MCTS(pf, A, c_puct=c_puct, n_playouts=S, use_dirichlet=use_dir, dirichlet_ratio=0.25,
+                             use_puct=False)
+        if leaf_update:
+            tree.update_root(prefix[-1])
+        if seed is not None:
+            np.random.seed(seed)
+        searches = []
+        for r in range(n_searches):
+            trace, eta = [], None
+            with RngTap() as tap:
+                if use_dir:
+                    tree.expand_root_dirichlet(state)
+                    eta = tap.etas[-1]
+                after_expand = root_stats(tree.root)
+                for _ in range(S):
+                    tree.playout(state.clone())
+                    trace.append(root_stats(tree.root))
+            final = trace[-1]
+            move = final["actions"][int(np.argmax(final["cN"]))]
+            searches.append({"eta": eta, "after_root_expand": after_expand, "trace_cN": [t["cN"] for t in trace],
+                             "trace_rootQ": [t["Q"] for t in trace], "final": final, "move": int(move),
+                             "root_use_puct": bool(tree.root.use_puct)})
+            state.apply_action(move)
+            if state.is_terminal():
+                break
+            tree.update_root(move)
+        cases.append({"game": game_name, "prefix": [int(a) for a in prefix], "n_playouts": S, "use_dirichlet": use_dir,
+                      "c_puct": c_puct, "dirichlet_ratio": 0.25, "salt": salt, "leaf_update": leaf_update,
+                      "searches": searches})
+    return cases
+
+
+SELFPLAY_NPA_SPECS = [  # num_probabilistic_actions (alphazerobot.py:36,81-86): sample the first n moves, then argmax
+    ("connect_four", 40, "on-policy", 1.0, {"num_probabilistic_actions": 6}, 41, 121),
+    ("connect_four", 30, "soft-Z", 1.0, {"num_probabilistic_actions": 0}, 42, 122),
+    ("breakthrough(rows=6,columns=6)", 30, "on-policy", 1.0, {"num_probabilistic_actions": 9}, 43, 123),
+]
+
+
+def gen_selfplay(ref, specs=None):
+    games = []
+    specs = specs or [
         # (game, n_playouts, backup, temperature, extra kwargs, salt, seed)
         ("connect_four", 50, "on-policy", 1.0, {}, 21, 101),
         ("connect_four", 25, "on-policy", 1.0, {}, 22, 102),
@@ -204,7 +272,9 @@ def gen_selfplay(ref):
         assert len(examples) == len(per_move)
         if kwargs.get("use_dirichlet", True):
             assert len(tap.etas) == len(per_move)
-        assert len(tap.us) == len(per_move)
+        n_sampled = min(len(per_move), max(0, kwargs.get("num_probabilistic_actions", 1000)))
+        assert len(tap.us) == n_sampled
+        tap.us.extend([0.0] * (len(per_move) - n_sampled))  # plies past num_probabilistic_actions: argmax, no draw
         games.append({
             "game": game_name, "kwargs": kwargs, "salt": salt, "seed": seed,
             "etas": tap.etas, "us": tap.us,
@@ -418,7 +488,9 @@ def main():
         print("wrote", name, os.path.getsize(os.path.join(GOLD, name)), "bytes")
 
     dump("mcts_trace.json", gen_mcts_traces(ref))
+    dump("mcts_trace_uct.json", gen_mcts_traces_uct(ref))
     dump("selfplay.json", gen_selfplay(ref))
+    dump("selfplay_npa.json", gen_selfplay(ref, SELFPLAY_NPA_SPECS))
     dump("remove_illegal.json", gen_remove_illegal(ref))
     for tag, blob in gen_rules().items():
         dump("rules_%s.json" % tag, blob)

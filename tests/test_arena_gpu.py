@@ -154,6 +154,68 @@ def test_zero_vs_zero_entry_points():
     assert len(out) == 3 and out[2] == {} and all(v in (-1.0, 0.0, 1.0) for v in out[:2])
 
 
+@pytest.mark.parametrize("game_name,opponent,S,sims,npa", [
+    ("connect_four", "random", 20, 0, 1000), ("connect_four", "uct", 16, 30, 3), ("breakthrough(rows=6,columns=6)", "random", 10, 0, 1000),
+])
+def test_probabilistic_arena_agent_equals_the_oracle(game_name, opponent, S, sims, npa):
+    """AlphaZeroBot(use_probabilistic_actions=True[, num_probabilistic_actions=n]) outside self-play (alphazerobot.py:34-36,
+    81-86; tournament.py:35-36): the agent samples its moves from the tempered visit distribution for the first n plies.
+    Same Philox move stream on both sides: the device games are the oracle's, move for move - and differ from the greedy agent's."""
+    from alphazero_openspiel_amd import arena, engine as E
+    n_games, salt, seed = 12, 6, 77
+    games = {}
+    for prob in (True, False):
+        eng = arena.arena_engine(game_name, 5, n_games, "zero", opponent, opponent_sims=sims, device=0, seed=seed, n_playouts=S,
+                                 use_probabilistic_actions=prob, num_probabilistic_actions=npa)
+        A = eng.A
+        ev = E.HostPolicyEvaluator(eng, lambda b: fakepolicy.fake_eval(b, A, salt))
+        ret0, prog, ex = arena.run_arena(eng, ev, n_games, use_graph=False, check_every=4)
+        eng.close()
+        assert prog["games_done"] == n_games and prog["error_flags"] == 0
+        games[prob] = [ex["move"][g, :int(ex["game_len"][g])].tolist() for g in range(n_games)]
+        for gid in range(n_games):
+            want = orc.play_arena_game(lambda b: fakepolicy.fake_eval(b, A, salt), game_name, gid, agent="zero", opponent=opponent,
+                                       opponent_sims=sims, n_playouts=S, seed=seed, use_probabilistic_actions=prob,
+                                       num_probabilistic_actions=npa)
+            assert games[prob][gid] == want["actions"], (gid, prob)
+            assert float(ret0[gid]) == want["ret0"]
+    assert games[True] != games[False]
+
+
+def test_generate_statistics_returns_both_search_trees_after_every_move():
+    """generate_statistics (game_utils.py:16-35,120-145; examplegenerator.py:192-193; tournament.py:39-52): per test
+    {"game1": {"player1": [{"root": Node}...], "player2": [...]}, "game2": ...}, keyed by network."""
+    from alphazero_openspiel_amd import game_utils
+    from alphazero_openspiel_amd.examplegenerator import ExampleGenerator
+    from alphazero_openspiel_amd.mcts import Node
+    net = _ckpt("connect_four", [3, 6, 7], 7).cuda()
+    S1, S2 = 24, 12
+    s1, s2, stats = game_utils.test_zero_vs_zero(net.predict, 0, "connect_four", generate_statistics=True,
+                                                 settings1=dict(n_playouts=S1, use_probabilistic_actions=True),
+                                                 settings2=dict(n_playouts=S2, use_probabilistic_actions=True))
+    assert s1 in (-1.0, 0.0, 1.0) and s2 in (-1.0, 0.0, 1.0) and set(stats) == {"game1", "game2"}
+    for key, first in (("game1", "player1"), ("game2", "player2")):  # network 1 moves first in game 1, second in game 2
+        g = stats[key]
+        n = len(g["player1"])
+        assert n == len(g["player2"]) and 7 <= n <= 42
+        second = "player2" if first == "player1" else "player1"
+        sims = {"player1": S1, "player2": S2}
+        r0, r1 = g[first][0]["root"], g[second][0]["root"]
+        assert isinstance(r0, Node) and sum(c.N for c in r0.children.values()) == sims[first] and r0.N == sims[first]
+        assert r1.is_leaf() and r1.N == 0                                # the second player has not searched yet
+        r1 = g[second][1]["root"]                                        # ... and has after its first move
+        assert sum(c.N for c in r1.children.values()) == sims[second]
+        assert g[first][1]["root"].N == g[first][0]["root"].N            # unchanged while the other player moved
+        deep = g[first][2]["root"]                                       # second search: the tree kept across two moves
+        assert deep.N >= sims[first] and any(not c.is_leaf() for c in deep.children.values())
+    gen = ExampleGenerator(net, "connect_four", torch.device("cuda:0"), is_test=True, generate_statistics=True, seed=3,
+                           settings1=dict(n_playouts=10), settings2=dict(n_playouts=10))
+    avg, st = gen.generate_tests(2, game_utils.test_zero_vs_zero, None)
+    assert -1.0 <= avg <= 1.0 and len(st) == 2 and all(set(x) == {"game1", "game2"} for x in st)
+    avg, st = gen.generate_tests(3, game_utils.test_zero_vs_mcts, 20)
+    assert -1.0 <= avg <= 1.0 and st == [None] * 3
+
+
 def test_arena_configuration_errors():
     from alphazero_openspiel_amd import engine as E
     with pytest.raises(E.EngineError):

@@ -189,8 +189,8 @@ def test_engine_refuses_cpu_devices():
         SelfPlayEngine("connect_four", 4, device="cpu")
     with pytest.raises(EngineError):
         ExampleGenerator(Net([3, 6, 7], 7), "connect_four", torch.device("cpu"))
-    with pytest.raises(NotImplementedError):
-        ExampleGenerator(Net([3, 6, 7], 7), "connect_four", torch.device("cuda:0"), generate_statistics=True)
+    with pytest.raises(EngineError):  # nothing in the package computes on the host, whatever the options
+        ExampleGenerator(Net([3, 6, 7], 7), "connect_four", torch.device("cpu"), is_test=True, generate_statistics=True)
 
 
 # ------------------------------------------------------------------------------------- multi-rank (gloo)

@@ -47,9 +47,44 @@ def test_mcts_trace_matches_reference(idx):
     assert (pi == want).all()
 
 
+@pytest.mark.parametrize("idx", range(6))
+def test_mcts_trace_use_puct_false_matches_reference(idx):
+    """MCTS(use_puct=False): mcts.py:80 runs only in trees update_root started from a leaf root (mcts.py:122,199-200)."""
+    case = load_golden("mcts_trace_uct.json")[idx]
+    s = _state_after(case["game"], case["prefix"])
+    m = orc.MCTS(_policy(s.num_actions, case["salt"]), case["game"], c_puct=case["c_puct"],
+                 n_playouts=case["n_playouts"], use_dirichlet=case["use_dirichlet"],
+                 dirichlet_ratio=case["dirichlet_ratio"], use_puct=False)
+    if case["leaf_update"]:
+        m.update_root(case["prefix"][-1])
+    for srch in case["searches"]:
+        if case["use_dirichlet"]:
+            m.expand_root_dirichlet(s, srch["eta"])
+        assert m.root_stats() == srch["after_root_expand"]
+        for k in range(case["n_playouts"]):
+            m.playout(s)
+            st = m.root_stats()
+            assert st["cN"] == srch["trace_cN"][k], "playout %d" % k
+            assert st["Q"] == srch["trace_rootQ"][k], "playout %d" % k
+        assert m.root_stats() == srch["final"]
+        s.apply_action(srch["move"])
+        if not s.is_terminal():
+            m.update_root(srch["move"])
+    assert any(not x["root_use_puct"] for x in case["searches"]) == case["leaf_update"]
+
+
 @pytest.mark.parametrize("idx", range(13))
 def test_play_game_self_matches_reference(idx):
-    g = load_golden("selfplay.json")[idx]
+    _check_play_game_self(load_golden("selfplay.json")[idx])
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_play_game_self_num_probabilistic_actions_matches_reference(idx):
+    """alphazerobot.py:36,81-86: sampled moves for the first n plies, argmax afterwards (n = 6, 0, 9)."""
+    _check_play_game_self(load_golden("selfplay_npa.json")[idx])
+
+
+def _check_play_game_self(g):
     kw = dict(g["kwargs"])
     game, rows, cols = orc.parse_game(g["game"])
     A = orc.lib().orc_num_actions(game, rows, cols)
