@@ -193,6 +193,18 @@ def test_engine_refuses_cpu_devices():
         ExampleGenerator(Net([3, 6, 7], 7), "connect_four", torch.device("cpu"), is_test=True, generate_statistics=True)
 
 
+def test_integration_md_binding_stub_matches_the_abi():
+    """The ctypes stub INTEGRATION.md shows a maintainer is the struct the library checks (struct_size guard)."""
+    import ctypes as C
+    import re
+    from alphazero_openspiel_amd import _lib
+    src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class AzConfig\(C.Structure\):.*?\n(?=\nlib\.)", src, re.S)
+    ns = {"C": C}
+    exec(m.group(0), ns)
+    assert list(ns["AzConfig"]._fields_) == list(_lib.AzConfig._fields_)
+
+
 # ------------------------------------------------------------------------------------- multi-rank (gloo)
 _WORKER = r"""
 import os, sys
