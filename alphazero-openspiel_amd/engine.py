@@ -290,26 +290,59 @@ def pi_from_visits(actions, visits, num_actions):
     return nv.tolist()
 
 
+def pis_from_visits(actions, visits, n_children, num_actions):
+    """pi_from_visits for many recorded plies at once: actions / visits [n, max_children], n_children [n] -> float64 [n, A].
+    Row for row the same IEEE operations in the same order (numpy reduces a C-contiguous last axis with the pairwise sum it
+    uses for a 1-D array; tests/test_host_logic.py checks the rows against pi_from_visits bit for bit)."""
+    n, mc = visits.shape
+    live = np.arange(mc)[None, :] < np.asarray(n_children).reshape(-1, 1)
+    v = np.where(live, visits, 0).astype(np.int64)
+    total = v.sum(axis=1)
+    frac = v.astype(np.float64) / np.where(total > 0, total, 1).astype(np.float64)[:, None]
+    rows = np.repeat(np.arange(n), mc).reshape(n, mc)
+    nv = np.zeros((n, num_actions), dtype=np.float64)
+    nv[rows[live], actions.astype(np.int64)[live]] = frac[live]
+    s = np.sum(nv, axis=1)
+    ok = s > 1e-6
+    out = np.zeros_like(nv)
+    out[ok] = nv[ok] / s[ok][:, None]
+    if not ok.all():  # no visit mass on any legal action: uniform over the children (alphazerobot.py:15-17)
+        bad = ~ok & (np.asarray(n_children).reshape(-1) > 0)
+        uni = np.zeros_like(nv)
+        cnt = np.asarray(n_children).reshape(-1).astype(np.float64)
+        sel = live & bad[:, None]
+        uni[rows[sel], actions.astype(np.int64)[sel]] = np.repeat(1.0 / cnt[bad], np.asarray(n_children).reshape(-1)[bad])
+        out[bad] = uni[bad]
+    return out
+
+
 def examples_from_export(game, ex, start_history=()):
     """Engine records -> the reference's list of games, each a list of `[info_state_str, board (C+1,H,W)
-    float64, pi list[A], value]` (game_utils.py:169,200-204; consumed by train.py:109-126,172-198)."""
+    float64, pi list[A], value]` (game_utils.py:169,200-204; consumed by train.py:109-126,172-198).
+    All plies of all games are converted in bulk (one numpy pass for boards, one for pi); what remains per example is
+    building its 4-element list."""
     A = game.num_distinct_actions()
-    games = []
     p0 = int(ex["start_ply"])
-    prefix = [int(a) for a in start_history]
-    for g in range(len(ex["game_len"])):
-        n = int(ex["game_len"][g])
-        sl = slice(p0, p0 + n)
-        boards = boards_from_bitboards(game, ex["states"][g, sl], np.arange(p0, p0 + n))
-        moves = ex["move"][g, sl].tolist()
-        plies = []
-        for i in range(n):
-            nc = int(ex["n_children"][g, p0 + i])
-            pi = pi_from_visits(ex["child_action"][g, p0 + i, :nc].astype(np.int64),
-                                ex["child_visits"][g, p0 + i, :nc], A)
-            key = ", ".join(str(a) for a in prefix + moves[:i])
-            plies.append([key, boards[i], pi, float(ex["value"][g, p0 + i])])
+    lens = np.asarray(ex["game_len"]).astype(np.int64)
+    G = len(lens)
+    if G == 0:
+        return []
+    mp = ex["move"].shape[1]
+    ply = np.arange(mp)[None, :]
+    valid = (ply >= p0) & (ply < p0 + lens[:, None])           # [G, mp], row-major = game by game, ply by ply
+    boards = boards_from_bitboards(game, ex["states"][valid], np.broadcast_to(ply, valid.shape)[valid])
+    pis = pis_from_visits(ex["child_action"][valid], ex["child_visits"][valid], ex["n_children"][valid], A).tolist()
+    values = ex["value"][valid].tolist()
+    moves = ex["move"][valid].tolist()
+    prefix = ", ".join(str(int(a)) for a in start_history)
+    games, k = [], 0
+    for n in lens.tolist():
+        key, plies = prefix, []
+        for i in range(k, k + n):
+            plies.append([key, boards[i], pis[i], values[i]])
+            key = (key + ", " if key else "") + str(moves[i])
         games.append(plies)
+        k += n
     return games
 
 

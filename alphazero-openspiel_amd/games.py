@@ -195,9 +195,8 @@ def legal_actions_from_bitboards(game, bb0, bb1, ply):
     return out
 
 
-def observation_planes(game, bbs):
-    """bbs: uint64 [n,2] -> float64 [n,3,H,W] observation planes (the old OpenSpiel layout the shipped
-    checkpoints pin: connect_four [empty, player-1, player-0]; breakthrough [black, white, empty])."""
+def _cell_bits(game, bbs):
+    """uint64 [n,2] bitboards -> two uint8 [n, H*W] arrays (player 0's / player 1's pieces) in the tensor's row-major cell order."""
     bbs = np.asarray(bbs, dtype=np.uint64).reshape(-1, 2)
     R, C = game.rows, game.cols
     if game.game_id == 0:
@@ -205,20 +204,35 @@ def observation_planes(game, bbs):
         shift = (cols * 7 + rows).astype(np.uint64).reshape(-1)
     else:
         shift = np.arange(R * C, dtype=np.uint64)
-    p0 = ((bbs[:, 0:1] >> shift[None, :]) & np.uint64(1)).astype(np.float64)
-    p1 = ((bbs[:, 1:2] >> shift[None, :]) & np.uint64(1)).astype(np.float64)
-    empty = 1.0 - p0 - p1
+    one = np.uint64(1)
+    return (((bbs[:, 0:1] >> shift[None, :]) & one).astype(np.uint8), ((bbs[:, 1:2] >> shift[None, :]) & one).astype(np.uint8))
+
+
+def _fill_planes(game, out, p0, p1):
+    """out float64 [n, >=3, H*W]: the observation planes (the old OpenSpiel layout the shipped checkpoints pin:
+    connect_four [empty, player-1, player-0]; breakthrough [black, white, empty])."""
+    empty = 1 - p0 - p1
     planes = (empty, p1, p0) if game.game_id == 0 else (p0, p1, empty)
-    return np.stack(planes, axis=1).reshape(-1, 3, R, C)
+    for k, pl in enumerate(planes):
+        out[:, k, :] = pl  # one cast-and-store pass per plane, no float temporaries
+
+
+def observation_planes(game, bbs):
+    """bbs: uint64 [n,2] -> float64 [n,3,H,W] observation planes."""
+    p0, p1 = _cell_bits(game, bbs)
+    out = np.empty((p0.shape[0], 3, game.rows * game.cols), dtype=np.float64)
+    _fill_planes(game, out, p0, p1)
+    return out.reshape(-1, 3, game.rows, game.cols)
 
 
 def boards_from_bitboards(game, bbs, plies):
     """state_to_board (reference network.py:9-18) for many recorded states at once:
     float64 [n,4,H,W], last plane = player to move (ply & 1)."""
-    obs = observation_planes(game, bbs)
-    plies = np.asarray(plies).reshape(-1)
-    cur = (plies & 1).astype(np.float64)[:, None, None, None] * np.ones((1, 1, game.rows, game.cols))
-    return np.concatenate([obs, cur], axis=1)
+    p0, p1 = _cell_bits(game, bbs)
+    out = np.empty((p0.shape[0], 4, game.rows * game.cols), dtype=np.float64)
+    _fill_planes(game, out, p0, p1)
+    out[:, 3, :] = (np.asarray(plies).reshape(-1) & 1)[:, None]
+    return out.reshape(-1, 4, game.rows, game.cols)
 
 
 def state_from_history(game, history):

@@ -74,6 +74,22 @@ def test_pi_from_visits_is_the_reference_arithmetic():
             assert pi_from_visits(acts, visits, A) == want.tolist()
 
 
+def test_bulk_pi_equals_the_per_ply_arithmetic_bit_for_bit():
+    """examples_from_export converts all plies of a generation in one numpy pass (pis_from_visits): every row must be the
+    per-ply pi_from_visits result exactly (same IEEE operations, numpy's pairwise sum per row), ragged child counts included."""
+    from alphazero_openspiel_amd.engine import pis_from_visits
+    rng = np.random.RandomState(3)
+    for A, mc in [(7, 7), (432, 36), (768, 48), (240, 24)]:
+        n = 400
+        nch = rng.randint(1, mc + 1, size=n)
+        acts = np.stack([np.sort(rng.choice(A, mc, replace=False)) for _ in range(n)]).astype(np.uint16)
+        vis = rng.randint(0, 2000, size=(n, mc)).astype(np.uint32)
+        vis[np.arange(n), 0] += 1
+        bulk = pis_from_visits(acts, vis, nch, A)
+        for i in range(n):
+            assert bulk[i].tolist() == pi_from_visits(acts[i, :nch[i]].astype(np.int64), vis[i, :nch[i]], A)
+
+
 def test_remove_illegal_actions_matches_reference_fixture():
     for case in load_golden("remove_illegal.json"):
         out = remove_illegal_actions(np.array(case["probs"], dtype=np.float64), list(case["legal"]))
