@@ -92,6 +92,8 @@ PROTOTYPES = [
     ("az_engine_set_start_prefix", C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32]),
     ("az_engine_advance", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("az_engine_advance_slots", C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
+    ("az_engine_compact_rows", C.c_int, [_vp, C.POINTER(C.c_int32), _vp]),
+    ("az_engine_advance_rows", C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp]),
     ("az_engine_opponent_moves", C.c_int, [_vp, _vp]),
     ("az_engine_exchange_moves", C.c_int, [_vp, _vp, _vp]),
     ("az_engine_update_root", C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32, _vp]),

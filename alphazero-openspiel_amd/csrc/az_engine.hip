@@ -453,7 +453,7 @@ __device__ __forceinline__ bool opponent_to_move(const Params &p, int gid, const
 // per tick; now moving slots run beside the other slots' playouts).
 template <int GAME>
 __device__ __forceinline__ void move_step(const Params &p, const int g, const int lane, int ph, SlotRegs sr,
-                                          float *__restrict__ obs_out) {
+                                          float *__restrict__ obs_row) { // obs_row: this slot's row of the request buffer
     const AzGeom &geom = p.geom;
     Pool t = pool_at(p, g, sr.half);
     unsigned long long st_moves = 0, st_evals = 0, st_compact = 0;
@@ -628,7 +628,7 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
             double inv = 1.0 / wave_sum_d(part);
             for (int j = 0; j < mine; j++) p.eta_buf[(size_t)g * p.maxc + k[j]] = eta[j] * inv;
         }
-        write_obs<GAME>(p, sr.rs, obs_out + (size_t)g * p.obs_elems, lane);
+        write_obs<GAME>(p, sr.rs, obs_row, lane);
         st_evals++;
         ph = PH_WAIT_ROOT;
     }
@@ -645,12 +645,17 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
 
 // ------------------------------------------------------------------------------------------------
 // The tick kernel.  Hot path: consume network results, then MCTS.playout until the network is needed again.
-template <int GAME, int NP>
+// MAPPED = false: the launch covers slots [g_first, g_end), row g of priors / values / obs_out belongs to slot g.
+// MAPPED = true (az_engine_advance_rows, the thinned-out tail of a generation): it covers the first g_end entries of the
+// dense list row_slot[]; entry i writes its request to row i, and reads the answer to its previous request from row req_row[g].
+template <int GAME, int NP, bool MAPPED>
 __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_first, const int g_end, const float *__restrict__ priors,
                                                          const float *__restrict__ values, float *__restrict__ obs_out) {
     const int lane = threadIdx.x & 63;
-    const int g = g_first + blockIdx.x * 4 + (threadIdx.x >> 6); // this launch covers slots [g_first, g_end)
-    if (g >= g_end) return;
+    const int row = g_first + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= g_end) return;
+    const int g = MAPPED ? rfl(p.row_slot[row]) : row;
+    float *__restrict__ const obs_row = obs_out + (size_t)row * p.obs_elems;
     // ---- 0. everything that is addressed by the slot index alone: ONE memory round trip ------------------------
     // (the kernel is a chain of dependent reads - PMC: waves parked in s_waitcnt 63 % of their life - so its duration
     //  is the number of round trips on the longest chain)
@@ -662,12 +667,14 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
     uint32_t path_raw[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) path_raw[i] = p.path[(size_t)g * p.pstride + i * 64 + lane];
-    const float value_raw = values ? values[g] : 0.f;
+    const int ans_row = MAPPED ? rfl(p.req_row[g]) : g;
+    const float value_raw = (values && !MAPPED) ? values[g] : 0.f;
     slot_load(p, g, sr);
     const int ph = rfl(ph_raw);
     if (ph == PH_MOVE || ph == PH_NEED_ROOT || ph == PH_OPP_DONE) { // the agent's move / the opponent's move / the next search's
                                                                     // root request: ends this slot's tick
-        move_step<GAME>(p, g, lane, ph, sr, obs_out);
+        if (MAPPED && lane == 0) p.req_row[g] = row;
+        move_step<GAME>(p, g, lane, ph, sr, obs_row);
         return;
     }
     if (ph != PH_RUN && ph != PH_WAIT_LEAF && ph != PH_WAIT_ROOT) return;
@@ -692,8 +699,9 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
         path.pn[0] = rootn.N;
         path.pq[0] = rootn.Q;
     }
+    const float value_ans = MAPPED ? ((values && (ph == PH_WAIT_LEAF || ph == PH_WAIT_ROOT)) ? values[ans_row] : 0.f) : value_raw;
     if (ph == PH_WAIT_LEAF || ph == PH_WAIT_ROOT) {
-        const float *pri = priors + (size_t)g * p.A;
+        const float *pri = priors + (size_t)ans_row * p.A;
         AzState ls;
         uint32_t node, node_act;
         int depth = 0;
@@ -766,7 +774,7 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
             st_nodes += (unsigned long long)n;
         }
         if (ph == PH_WAIT_LEAF) { // mcts.py:152: node.update_recursive(-leaf_value)
-            float vf = value_raw;
+            float vf = value_ans;
             if (!(vf == vf)) fault |= AZ_FAULT_BAD_PRIOR;
             backup_path<NP>(t, path, depth, -(double)vf, lane);
             root_n++;
@@ -854,9 +862,10 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
             continue;
         }
         // non-terminal leaf: ask the network (mcts.py:146)
-        write_obs<GAME>(p, s, obs_out + (size_t)g * p.obs_elems, lane);
+        write_obs<GAME>(p, s, obs_row, lane);
         st_evals++;
         if (lane == 0) {
+            if (MAPPED) p.req_row[g] = row;
             p.leaf_bb0[g] = s.bb0;
             p.leaf_bb1[g] = s.bb1;
             p.leaf_ply[g] = s.ply;
@@ -1274,6 +1283,7 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     int rc = AZ_OK;
 #define DA(ptr, n) if (rc == AZ_OK) rc = dalloc(e, &(ptr), (n))
     DA(p.nodes, nodes);
+    DA(p.row_slot, G); DA(p.req_row, G); DA(p.n_rows_live, 1);
     DA(p.phase, G); DA(p.gid, G); DA(p.ply, G); DA(p.sims, G); DA(p.which, G); DA(p.depth, G); DA(p.leaf_ply, G);
     DA(p.root, G); DA(p.alloc, G); DA(p.leaf_node, G); DA(p.path, G * p.pstride);
     DA(p.bb0, G); DA(p.bb1, G); DA(p.leaf_bb0, G); DA(p.leaf_bb1, G);
@@ -1340,6 +1350,8 @@ extern "C" int az_engine_reset(az_engine *e, uint64_t seed, int64_t n_games, voi
     HIPCHK(e, hipGetLastError());
     e->reset_done = true;
     e->ticks = 0;
+    e->rows_mapped = false;
+    e->rows_live = 0;
     return AZ_OK;
 }
 
@@ -1405,17 +1417,47 @@ extern "C" int az_engine_set_start_prefix(az_engine *e, const int32_t *actions, 
     return AZ_OK;
 }
 
+template <bool MAPPED>
 static int advance_range(az_engine *e, int g_first, int g_end, const float *priors, const float *values, float *obs_out, void *stream) {
     HIPCHK(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((g_end - g_first + 3) / 4), block(256);
     if (e->cfg.game == AZ_GAME_CONNECT_FOUR) {
-        hipLaunchKernelGGL((az_advance_kernel<AZG_CONNECT_FOUR, 1>), grid, block, 0, st, e->p, g_first, g_end, priors, values, obs_out);
+        hipLaunchKernelGGL((az_advance_kernel<AZG_CONNECT_FOUR, 1, MAPPED>), grid, block, 0, st, e->p, g_first, g_end, priors, values, obs_out);
     } else {
-        hipLaunchKernelGGL((az_advance_kernel<AZG_BREAKTHROUGH, 3>), grid, block, 0, st, e->p, g_first, g_end, priors, values, obs_out);
+        hipLaunchKernelGGL((az_advance_kernel<AZG_BREAKTHROUGH, 3, MAPPED>), grid, block, 0, st, e->p, g_first, g_end, priors, values, obs_out);
     }
     HIPCHK(e, hipGetLastError());
     return AZ_OK;
+}
+
+// The slots that still play, in slot order, as a dense list (one workgroup: a block-wide prefix sum over the phase flags).
+__global__ __launch_bounds__(1024) void az_compact_rows_kernel(Params p, int first_time) {
+    __shared__ int wave_tot[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int g0 = 0; g0 < p.G; g0 += 1024) {
+        const int g = g0 + tid;
+        const bool live = g < p.G && p.phase[g] != PH_IDLE;
+        if (first_time && g < p.G) p.req_row[g] = g; // until now row g held slot g's request
+        const unsigned long long m = __ballot(live);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; w++) off += wave_tot[w];
+        if (live) p.row_slot[off + before] = g;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += wave_tot[w];
+            base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *p.n_rows_live = base;
 }
 
 static int advance_checks(az_engine *e, const float *obs_out) {
@@ -1439,7 +1481,58 @@ extern "C" int az_engine_advance(az_engine *e, const float *priors, const float 
         e->err = "az_engine_advance: priors/values may be NULL only on the first tick after reset";
         return AZ_E_INVALID;
     }
-    rc = advance_range(e, 0, e->p.G, priors, values, obs_out, stream);
+    if (e->rows_mapped) {
+        e->err = "az_engine_advance after az_engine_compact_rows: the requests now live in dense rows, use az_engine_advance_rows";
+        return AZ_E_STATE;
+    }
+    rc = advance_range<false>(e, 0, e->p.G, priors, values, obs_out, stream);
+    if (rc == AZ_OK) e->ticks++;
+    return rc;
+}
+
+extern "C" int az_engine_compact_rows(az_engine *e, int32_t *n_live_out, void *stream) {
+    if (!e || !n_live_out) return AZ_E_INVALID;
+    if (!e->reset_done || e->ticks == 0) {
+        e->err = "az_engine_compact_rows before the first tick";
+        return AZ_E_STATE;
+    }
+    if (e->p.arena_agent != AZ_ARENA_SELF_PLAY || e->cfg.manual_moves) {
+        e->err = "az_engine_compact_rows is for self-play engines (arena slots wait for each other; manual slots are re-armed)";
+        return AZ_E_STATE;
+    }
+    unsigned long long next = 0;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(e, hipStreamSynchronize(st));
+    HIPCHK(e, hipMemcpy(&next, e->p.next_game, sizeof next, hipMemcpyDeviceToHost));
+    if ((long long)next < e->n_games) {
+        e->err = "az_engine_compact_rows: games are still being handed out (idle slots would be refilled outside the list)";
+        return AZ_E_STATE;
+    }
+    hipLaunchKernelGGL(az_compact_rows_kernel, dim3(1), dim3(1024), 0, st, e->p, e->rows_mapped ? 0 : 1);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(st));
+    int n = 0;
+    HIPCHK(e, hipMemcpy(&n, e->p.n_rows_live, sizeof n, hipMemcpyDeviceToHost));
+    e->rows_mapped = true;
+    e->rows_live = n;
+    *n_live_out = n;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_advance_rows(az_engine *e, int32_t n_rows, const float *priors, const float *values, float *obs_out, void *stream) {
+    int rc = advance_checks(e, obs_out);
+    if (rc != AZ_OK) return rc;
+    if (!e->rows_mapped || !priors || !values) {
+        e->err = "az_engine_advance_rows needs az_engine_compact_rows first, and priors / values";
+        return AZ_E_STATE;
+    }
+    if (n_rows < e->rows_live || n_rows > e->p.G) {
+        e->err = "az_engine_advance_rows: n_rows must cover the live slots (az_engine_compact_rows' count) and fit n_slots";
+        return AZ_E_INVALID;
+    }
+    if (e->rows_live == 0) return AZ_OK;
+    rc = advance_range<true>(e, 0, e->rows_live, priors, values, obs_out, stream);
     if (rc == AZ_OK) e->ticks++;
     return rc;
 }
@@ -1452,7 +1545,11 @@ extern "C" int az_engine_advance_slots(az_engine *e, int32_t first_slot, int32_t
         e->err = "az_engine_advance_slots: slot range outside [0, n_slots) or NULL priors/values";
         return AZ_E_INVALID;
     }
-    rc = advance_range(e, first_slot, first_slot + n_slots, priors, values, obs_out, stream);
+    if (e->rows_mapped) {
+        e->err = "az_engine_advance_slots after az_engine_compact_rows: use az_engine_advance_rows";
+        return AZ_E_STATE;
+    }
+    rc = advance_range<false>(e, first_slot, first_slot + n_slots, priors, values, obs_out, stream);
     if (rc == AZ_OK) e->ticks++;
     return rc;
 }

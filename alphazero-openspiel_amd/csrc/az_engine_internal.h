@@ -50,6 +50,9 @@ struct Params {
     uint32_t *root, *alloc, *leaf_node, *path;
     uint64_t *bb0, *bb1, *leaf_bb0, *leaf_bb1;
     unsigned long long *stats; // [G][ST_N]
+    // dense rows (tail of a generation): row_slot[i] = the i-th slot that still plays, req_row[g] = the row of the request /
+    // answer buffers that holds slot g's outstanding request; n_rows_live (device) = length of the list
+    int *row_slot, *req_row, *n_rows_live;
     // global counters
     unsigned long long *next_game, *games_done;
     unsigned int *faults;
@@ -90,6 +93,8 @@ struct az_engine {
     int *d_actions = nullptr;
     int64_t ticks = 0;
     int64_t inj_games = 0;
+    bool rows_mapped = false; // az_engine_compact_rows has been called since the last reset
+    int rows_live = 0;
     // host mirrors for export
     std::vector<int32_t> h_len;
     std::vector<float> h_ret0;

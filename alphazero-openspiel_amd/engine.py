@@ -164,6 +164,20 @@ class SelfPlayEngine:
                                                      self._ptr(priors, (self.G, self.A)), self._ptr(values, (self.G,)),
                                                      self._ptr(obs, (self.G,) + self.obs_shape), self._stream()))
 
+    def compact_rows(self):
+        """Tail of a generation (every game handed out): list the slots that still play and switch the request buffers to
+        dense rows -> the number of live slots.  Afterwards tick with advance_rows(n_rows >= that number, ...)."""
+        n = C.c_int32(0)
+        self._check(self.lib.az_engine_compact_rows(self._h, C.byref(n), self._stream()))
+        return int(n.value)
+
+    def advance_rows(self, n_rows, priors, values, obs):
+        """One tick over the dense list: priors / values / obs are the whole-engine tensors, only their first n_rows rows
+        are used (evaluate just those: evaluator(obs[:n_rows], priors[:n_rows], values[:n_rows]))."""
+        self._check(self.lib.az_engine_advance_rows(self._h, int(n_rows), self._ptr(priors, (self.G, self.A)),
+                                                    self._ptr(values, (self.G,)),
+                                                    self._ptr(obs, (self.G,) + self.obs_shape), self._stream()))
+
     def opponent_moves(self):
         """Arena engines: let the opponent bot choose its move in every slot where it is to move (applied by the next advance)."""
         self._check(self.lib.az_engine_opponent_moves(self._h, self._stream()))
@@ -386,9 +400,10 @@ class HostPolicyEvaluator:
     def __call__(self, obs, priors_out, values_out):
         e = self.engine
         boards = obs.detach().cpu().numpy().astype(np.float64)
-        pri = np.empty((e.G, e.A), dtype=np.float32)
-        val = np.empty((e.G,), dtype=np.float32)
-        for g in range(e.G):
+        n = boards.shape[0]  # all slots, or the dense rows of a thinned-out generation
+        pri = np.empty((n, e.A), dtype=np.float32)
+        val = np.empty((n,), dtype=np.float32)
+        for g in range(n):
             p, v = self.board_fn(boards[g])
             pri[g] = np.asarray(p, dtype=np.float32)
             val[g] = np.float32(v)
@@ -407,8 +422,14 @@ def slot_groups(n_slots, k):
     return groups
 
 
+def _tail_levels(n_slots):
+    """Row counts worth switching to as a generation thins out: the fused tower runs 256 workgroups of 8 (4) boards per round,
+    so its time steps down at n_slots/2 and n_slots/4 (4096 boards 202 us, 2048: 109 us, 1024: 72 us, 512: 66 us)."""
+    return [n for n in (n_slots // 2, n_slots // 4) if n >= 512]
+
+
 def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_ticks=None, use_graph=False,
-                 on_tick=None, overlap=1, ticks_per_graph=16):
+                 on_tick=None, overlap=1, ticks_per_graph=16, compact_tail=True):
     """ExampleGenerator.run_games without processes: tick the engine until n_games are finished.
     Returns the final progress dict.
 
@@ -416,13 +437,30 @@ def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_tick
     groups, each with its own HIP stream (and graph) ticking [az_engine_advance_slots, PV-net forward of the group]; a
     group's tree search and launch gaps then run beside another group's forward.  `evaluator` must then be a list of k
     evaluators, one per group (a FusedNet owns its intermediate buffers).  The games do not depend on the grouping:
-    random streams are keyed by game id."""
+    random streams are keyed by game id.
+
+    compact_tail: once every game has been handed to a slot the batch thins out (a generation lasts as long as its longest
+    game); when at most half / a quarter of the slots still play, the engine switches to dense request rows
+    (az_engine_compact_rows / az_engine_advance_rows) and the network evaluates only those rows.  The games are the same
+    (a board's evaluation does not depend on its row)."""
     if overlap > 1:
         return _run_selfplay_overlapped(engine, evaluator, n_games, seed, check_every, max_ticks, use_graph, overlap)
     engine.reset(n_games, seed)
     obs, pri, val = engine.alloc_io()
     ticks = 0
     graph = None
+    n_first = min(int(n_games), engine.G)  # games handed out by the reset
+    levels = _tail_levels(engine.G) if (compact_tail and on_tick is None) else []
+    rows = None  # None: one row per slot
+
+    def tick():
+        if rows is None:
+            engine.advance(pri, val, obs)
+            evaluator(obs, pri, val)
+        else:
+            engine.advance_rows(rows, pri, val, obs)
+            evaluator(obs[:rows], pri[:rows], val[:rows])
+
     if use_graph:
         # one tick = [az_advance_kernel, net.forward] replayed as a HIP graph
         torch.cuda.synchronize(engine.device)
@@ -430,8 +468,7 @@ def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_tick
         side.wait_stream(torch.cuda.current_stream(engine.device))
         with torch.cuda.stream(side):
             for _ in range(2):  # warm-up (MIOpen / workspace allocation must happen outside capture)
-                engine.advance(pri, val, obs)
-                evaluator(obs, pri, val)
+                tick()
                 ticks += 1
         torch.cuda.current_stream(engine.device).wait_stream(side)
         torch.cuda.synchronize(engine.device)
@@ -440,25 +477,40 @@ def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_tick
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             for _ in range(tpg):
-                engine.advance(pri, val, obs)
-                evaluator(obs, pri, val)
+                tick()
+    compactions = 0
     while True:
         for _ in range(check_every if graph is None else max(1, check_every // tpg)):
             if graph is not None:
                 graph.replay()
                 ticks += tpg
             else:
-                engine.advance(pri, val, obs)
-                evaluator(obs, pri, val)
+                tick()
                 ticks += 1
             if on_tick is not None:
                 on_tick(engine, ticks)
-        if engine.games_done() >= n_games:
+        done = engine.games_done()
+        if done >= n_games:
             break
         if max_ticks is not None and ticks >= max_ticks:
             raise EngineError("self-play did not finish within %d ticks: %r" % (max_ticks, engine.progress()))
+        # the tail: every game handed out (a finished slot took the next id until they ran out) and few slots still playing
+        if levels and min(n_games, n_first + done) >= n_games and n_games - done <= levels[0]:
+            live = engine.compact_rows()
+            while levels and live <= levels[0]:
+                rows = levels.pop(0)
+            compactions += 1
+            if graph is not None:  # re-capture for the new row count (one eager tick first: new kernel variants set their
+                tick()             # attributes on first use, which must not happen inside a capture)
+                ticks += 1
+                torch.cuda.synchronize(engine.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    for _ in range(tpg):
+                        tick()
     prog = engine.progress()
     prog["ticks"] = ticks
+    prog["tail_compactions"] = compactions
     return prog
 
 

@@ -228,6 +228,17 @@ int az_engine_advance_slots(az_engine *e, int32_t first_slot, int32_t n_slots, c
  * One arena tick = az_engine_advance, az_engine_opponent_moves, PV-net forward.  Asynchronous on `stream`. */
 int az_engine_opponent_moves(az_engine *e, void *stream);
 
+/* The tail of a generation.  Once every game has been handed to a slot, finished slots stay idle and the batch thins out while a
+ * tick still spans all n_slots rows of the request buffers (a generation lasts as long as its longest game).
+ * az_engine_compact_rows (synchronises `stream`) lists the slots that still play, densely and in slot order, and returns their
+ * number; from then on the engine is ticked with az_engine_advance_rows over n_rows >= that number rows: list entry i writes its
+ * request to row i of obs_out and finds the answer to its previous request in the row it was written to, so the network only has to
+ * evaluate the first n_rows rows (`az_net_forward(..., n_rows, ...)`).  May be called again as the list thins further; refused
+ * while games are still being handed out, and on arena / manual_moves engines.  az_engine_reset returns to one row per slot.
+ * Replaces nothing in the reference (its worker processes simply exit, examplegenerator.py:134-138). */
+int az_engine_compact_rows(az_engine *e, int32_t *n_live_out, void *stream);
+int az_engine_advance_rows(az_engine *e, int32_t n_rows, const float *priors, const float *values, float *obs_out, void *stream);
+
 /* Two arena engines facing each other (both AZ_OPPONENT_EXTERNAL, same game, same n_slots, arena_flip 0 and 1, games = slots:
  * no refill): for every slot, hand a's agent move to b and b's to a as soon as it has been played.  One tick of such a
  * pairing = advance(a), advance(b), az_engine_exchange_moves(a, b), forward(net of a), forward(net of b). */
