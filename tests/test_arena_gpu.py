@@ -182,6 +182,25 @@ def test_probabilistic_arena_agent_equals_the_oracle(game_name, opponent, S, sim
     assert games[True] != games[False]
 
 
+def test_use_puct_false_changes_nothing_in_arena_games_from_the_initial_position():
+    """MCTS(use_puct=False) only governs trees that update_root starts from a LEAF root (mcts.py:122,199-200).  A bot that plays
+    from the initial position never meets one (first step: no update_root with < 2 moves played, alphazerobot.py:62-64; later
+    steps: the root it re-roots from has been searched) - so, as in the reference (test_mcts.py:44-79 plots four PUCT curves),
+    the games are the same with either setting, agent first or second."""
+    from alphazero_openspiel_amd import arena, engine as E
+    n_games, salt = 10, 4
+    moves = {}
+    for use_puct in (True, False):
+        eng = arena.arena_engine("connect_four", 5, n_games, "zero", "random", device=0, seed=31, n_playouts=24, use_puct=use_puct)
+        A = eng.A
+        ev = E.HostPolicyEvaluator(eng, lambda b: fakepolicy.fake_eval(b, A, salt))
+        ret0, prog, ex = arena.run_arena(eng, ev, n_games, use_graph=False, check_every=4)
+        eng.close()
+        assert prog["error_flags"] == 0
+        moves[use_puct] = [ex["move"][g, :int(ex["game_len"][g])].tolist() for g in range(n_games)]
+    assert moves[True] == moves[False]
+
+
 def test_generate_statistics_returns_both_search_trees_after_every_move():
     """generate_statistics (game_utils.py:16-35,120-145; examplegenerator.py:192-193; tournament.py:39-52): per test
     {"game1": {"player1": [{"root": Node}...], "player2": [...]}, "game2": ...}, keyed by network."""
