@@ -1,0 +1,72 @@
+"""Randomised differential test: the HIP engine against the C oracle over the whole option space of play_game_self
+(game_utils.py:148-206) - game and board size, playouts, slots vs games (refill), value target, temperature, tree reuse, root
+noise, c_puct, dirichlet_ratio, num_probabilistic_actions, use_puct, node-pool size (compaction), chained-playout limits.
+Same fake policy, same injected random draws on both sides: every move, visit vector, pi, value target and counter must be equal
+(integers and IEEE doubles compared with ==).  Seeds are fixed, so a failure names its configuration."""
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from oracle import fakepolicy
+
+pytestmark = pytest.mark.gpu
+
+GAMES = ["connect_four", "connect_four", "breakthrough(rows=5,columns=4)", "breakthrough(rows=6,columns=6)",
+         "breakthrough(rows=4,columns=5)", "breakthrough(rows=6,columns=3)"]
+
+
+def _config(seed):
+    r = np.random.RandomState(1000 + seed)
+    game = GAMES[r.randint(len(GAMES))]
+    use_dirichlet = bool(r.rand() < 0.75)
+    S = int(r.randint(2 if not use_dirichlet else 1, 40))
+    n_games = int(r.randint(1, 6))
+    kw = dict(n_playouts=S, use_dirichlet=use_dirichlet, backup=["on-policy", "soft-Z", "A0C", "off-policy"][r.randint(4)],
+              temperature=[1.0, 1.0, 0.5, 2.0][r.randint(4)], keep_search_tree=bool(r.rand() < 0.8),
+              c_puct=float(r.choice([0.5, 1.0, 2.5, 4.0])), dirichlet_ratio=float(r.choice([0.1, 0.25, 0.5])),
+              num_probabilistic_actions=int(r.choice([1000, 1000, 0, 3, 7])), use_puct=bool(r.rand() < 0.8))
+    eng_only = dict(max_sims_per_tick=int(r.choice([0, 1, 3])), chain_window_us=int(r.choice([0, -1, 2])))
+    return game, n_games, int(r.randint(1, n_games + 1)), int(r.randint(100)), bool(r.rand() < 0.3), kw, eng_only, r
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AZ_FUZZ_N", "24"))))  # AZ_FUZZ_N=600 for a long hunt
+def test_random_configuration_equals_the_oracle(seed):
+    from test_engine_parity import _run_games
+    from alphazero_openspiel_amd import engine as E
+    game, n_games, n_slots, salt, small_pool, kw, eng_only, r = _config(seed)
+    gid, rows, cols = orc.parse_game(game)
+    A = orc.lib().orc_num_actions(gid, rows, cols)
+    mp = orc.max_plies(gid, rows, cols)
+    mc = min(64, 6 * cols) if gid else 7
+    etas, us, want = [], [], []
+    for _ in range(n_games):
+        e = [r.dirichlet(0.3 * np.ones(3 * rows * cols)).tolist() for _ in range(mp)]
+        u = r.random_sample(mp).tolist()
+        etas.append(e)
+        us.append(u)
+        want.append(orc.play_game_self(lambda b: fakepolicy.fake_eval(b, A, salt), game, etas=e, us=u, **kw))
+    eta_rows = [[row[:mc] for row in e] for e in etas]
+    if small_pool:  # three searches' worth of nodes: re-rooting has to compact
+        try:
+            games, ex, prog = _run_games(E, game, n_games, n_slots, salt, eta_rows, us, **kw, **eng_only,
+                                         nodes_per_slot=3 * (kw["n_playouts"] + 1) * mc + 80)
+        except E.EngineError as err:  # a kept subtree can outgrow any fixed pool: the engine says so (fault), it does not
+            assert "POOL_EXHAUSTED" in str(err)  # play on - then the configuration is checked with the default pool
+            small_pool = False
+    if not small_pool:
+        games, ex, prog = _run_games(E, game, n_games, n_slots, salt, eta_rows, us, **kw, **eng_only)
+    assert prog["error_flags"] == 0, (seed, game, kw, eng_only)
+    for i in range(n_games):
+        n = len(want[i]["actions"])
+        assert int(ex["game_len"][i]) == n, (seed, game, kw)
+        assert ex["move"][i, :n].tolist() == want[i]["actions"], (seed, game, kw)
+        assert float(ex["game_ret0"][i]) == want[i]["ret0"]
+        for j in range(n):
+            nc = int(ex["n_children"][i, j])
+            assert ex["child_visits"][i, j, :nc].tolist() == want[i]["root_cN"][j], (seed, i, j)
+            assert games[i][j][2] == want[i]["examples"][j][2], (seed, i, j)
+            assert games[i][j][3] == want[i]["examples"][j][3], (seed, i, j, kw["backup"])
+            assert (games[i][j][1] == want[i]["examples"][j][1]).all()
+    for key, okey in (("sims", "sims"), ("evals", "evals"), ("sum_depth", "sum_depth"), ("terminal_hits", "terminal_hits"),
+                      ("sum_children", "sum_children")):
+        assert prog[key] == sum(w["counters"][okey] for w in want), (seed, key)
