@@ -70,3 +70,36 @@ def test_random_configuration_equals_the_oracle(seed):
     for key, okey in (("sims", "sims"), ("evals", "evals"), ("sum_depth", "sum_depth"), ("terminal_hits", "terminal_hits"),
                       ("sum_children", "sum_children")):
         assert prog[key] == sum(w["counters"][okey] for w in want), (seed, key)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AZ_FUZZ_ARENA_N", "12"))))
+def test_random_arena_configuration_equals_the_oracle(seed):
+    """The evaluation arena (game_utils.py:16-117) over its options: agent (search / raw net), opponent (random / UCT rollout bot and
+    its simulation count), playouts, c_puct, temperature, tree reuse, sampled or greedy agent moves, slots vs games."""
+    from alphazero_openspiel_amd import arena, engine as E
+    r = np.random.RandomState(5000 + seed)
+    game = GAMES[r.randint(len(GAMES))]
+    agent = "zero" if r.rand() < 0.7 else "net"
+    opponent = "uct" if r.rand() < 0.5 else "random"
+    sims = int(r.randint(2, 40)) if opponent == "uct" else 0
+    n_games = int(r.randint(2, 9))
+    n_slots = int(r.randint(1, n_games + 1))
+    salt, eng_seed = int(r.randint(100)), int(r.randint(1 << 30))
+    kw = dict(n_playouts=int(r.randint(2, 30)), c_puct=float(r.choice([0.5, 1.0, 2.5, 4.0])),
+              temperature=float(r.choice([1.0, 1.0, 0.5, 2.0])), keep_search_tree=bool(r.rand() < 0.8),
+              use_probabilistic_actions=bool(r.rand() < 0.4), num_probabilistic_actions=int(r.choice([1000, 2, 5])))
+    uct_c = float(r.choice([1.0, 1.0, 0.5, 2.0]))
+    eng = arena.arena_engine(game, n_slots, n_games, agent, opponent, opponent_sims=sims, device=0, seed=eng_seed,
+                             opponent_uct_c=uct_c, **kw)
+    A = eng.A
+    ev = E.HostPolicyEvaluator(eng, lambda b: fakepolicy.fake_eval(b, A, salt))
+    ret0, prog, ex = arena.run_arena(eng, ev, n_games, use_graph=False, check_every=4)
+    eng.close()
+    assert prog["games_done"] == n_games and prog["error_flags"] == 0
+    okw = dict(kw) if agent == "zero" else {}
+    for gid in range(n_games):
+        want = orc.play_arena_game(lambda b: fakepolicy.fake_eval(b, A, salt), game, gid, agent=agent, opponent=opponent,
+                                   opponent_sims=sims, seed=eng_seed, opponent_uct_c=uct_c, **okw)
+        n = int(ex["game_len"][gid])
+        assert ex["move"][gid, :n].tolist() == want["actions"], (seed, gid, game, agent, opponent, kw)
+        assert float(ret0[gid]) == want["ret0"]
