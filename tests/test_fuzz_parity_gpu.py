@@ -103,3 +103,47 @@ def test_random_arena_configuration_equals_the_oracle(seed):
         n = int(ex["game_len"][gid])
         assert ex["move"][gid, :n].tolist() == want["actions"], (seed, gid, game, agent, opponent, kw)
         assert float(ret0[gid]) == want["ret0"]
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AZ_FUZZ_FACADE_N", "10"))))
+def test_random_mcts_call_sequence_equals_the_oracle(seed):
+    """The MCTS object as a caller may drive it (mcts.py:92-203): update_root before the first search (leaf root -> the tree takes
+    MCTS.use_puct, mcts.py:199-200), searches, repeated searches at one root (mcts.py:164-180), update_root along a random line of
+    play - façade over a one-slot device engine against the oracle's MCTS, root statistics compared after every call."""
+    from alphazero_openspiel_amd import games
+    from alphazero_openspiel_amd.mcts import MCTS
+    from alphazero_openspiel_amd.network import state_to_board
+    r = np.random.RandomState(9000 + seed)
+    name = GAMES[r.randint(len(GAMES))]
+    game = games.load_game(name)
+    A, shape = game.num_distinct_actions(), game.information_state_normalized_vector_shape()
+    salt = int(r.randint(100))
+    kw = dict(c_puct=float(r.choice([0.5, 1.0, 2.5, 4.0])), n_playouts=int(r.randint(2, 40)), use_dirichlet=False,
+              use_puct=bool(r.rand() < 0.5))
+    m = MCTS(fakepolicy.make_policy_fn(state_to_board, shape, A, salt), A, **kw)
+    o = orc.MCTS(lambda b: fakepolicy.fake_eval(b, A, salt), name, **kw)
+    s, so = game.new_initial_state(), orc.State(name)
+    for _ in range(int(r.randint(0, 4))):  # a random opening before the tree is touched
+        a = int(r.choice(s.legal_actions()))
+        s.apply_action(a)
+        so.apply_action(a)
+    if s.history() and r.rand() < 0.7:  # update_root on the untouched (leaf) root
+        m.update_root(s.history()[-1])
+        o.update_root(s.history()[-1])
+    for step in range(int(r.randint(2, 6))):
+        if s.is_terminal():
+            break
+        for _ in range(1 + int(r.rand() < 0.25)):  # sometimes search twice at the same root
+            pi = m.search(s)
+            want = o.search(so)
+            assert list(pi) == want.tolist(), (seed, step, name, kw)
+        got, rs = m.root, o.root_stats()
+        assert got.N == rs["N"] and sorted(got.children) == rs["actions"]
+        assert [got.children[a].N for a in rs["actions"]] == rs["cN"]
+        assert [got.children[a].Q for a in rs["actions"]] == rs["cQ"] and [got.children[a].P for a in rs["actions"]] == rs["cP"]
+        a = int(r.choice(s.legal_actions()))
+        s.apply_action(a)
+        so.apply_action(a)
+        if not s.is_terminal():
+            m.update_root(a)
+            o.update_root(a)
