@@ -147,3 +147,45 @@ def test_random_mcts_call_sequence_equals_the_oracle(seed):
         if not s.is_terminal():
             m.update_root(a)
             o.update_root(a)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AZ_FUZZ_NET_N", "10"))))
+def test_random_net_shape_matches_torch(seed):
+    """The fused tower + head over random architectures the reference's Net admits (network.py:21-64: any depth, <= 56 filters
+    here), boards and batch sizes, both precisions, against the PyTorch fp32 forward of the same weights on the CPU.
+    Tolerances: f16 mode 4e-3 / 8e-3 (tests/test_fused_net.py), fp32-grade mode 2e-5."""
+    import torch
+    from test_fused_net import _random_boards
+    from alphazero_openspiel_amd import fusednet, games
+    from alphazero_openspiel_amd.network import Net
+    r = np.random.RandomState(13000 + seed)
+    if r.rand() < 0.35:
+        name = "connect_four"
+    else:
+        rows, cols = int(r.randint(4, 9)), int(r.randint(3, 9))
+        name = "breakthrough(rows=%d,columns=%d)" % (rows, cols)
+    game = games.load_game(name)
+    shape, A = game.information_state_normalized_vector_shape(), game.num_distinct_actions()
+    blocks, filters = int(r.randint(1, 13)), int(r.choice([8, 16, 24, 32, 40, 48, 50, 50, 56, int(r.randint(8, 57))]))
+    n = int(r.choice([1, 3, int(r.randint(1, 64)), int(r.randint(64, 700)), int(r.randint(700, 2600))]))
+    precision = "f16" if r.rand() < 0.5 else "f32x"
+    torch.manual_seed(int(r.randint(1 << 30)))
+    net = Net(shape, A, n_blocks=blocks, n_filters=filters).eval()
+    boards = _random_boards(game, n, seed)
+    with torch.no_grad():
+        p, v = net(torch.from_numpy(boards))
+    try:
+        fn = fusednet.FusedNet(net, "cuda:0", max_boards=max(n, 16), precision=precision)
+    except RuntimeError as err:  # the documented limit of the fp32-grade mode (DESIGN.md section 7): its LDS budget
+        assert precision == "f32x" and filters > 50 and shape[1] * shape[2] > 48, (name, blocks, filters, str(err))
+        pytest.skip("f32x: 51-56 filters on a > 48-cell board do not fit (az_net_create says so)")
+    pf, vf = fn.forward(torch.from_numpy(boards).cuda())
+    torch.cuda.synchronize()
+    pf, vf = pf.cpu().numpy(), vf.cpu().numpy()
+    fn.close()
+    cfg = (name, blocks, filters, n, precision)
+    assert np.isfinite(pf).all() and np.isfinite(vf).all(), cfg
+    assert np.abs(pf.sum(1) - 1).max() < 1e-5, cfg
+    dp, dv = np.abs(pf - p.numpy()).max(), np.abs(vf - v.numpy()[:, 0]).max()
+    tol_p, tol_v = (4e-3, 8e-3) if precision == "f16" else (2e-5, 2e-5)
+    assert dp <= tol_p and dv <= tol_v, (cfg, dp, dv)
