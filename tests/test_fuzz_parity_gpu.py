@@ -189,3 +189,38 @@ def test_random_net_shape_matches_torch(seed):
     dp, dv = np.abs(pf - p.numpy()).max(), np.abs(vf - v.numpy()[:, 0]).max()
     tol_p, tol_v = (4e-3, 8e-3) if precision == "f16" else (2e-5, 2e-5)
     assert dp <= tol_p and dv <= tol_v, (cfg, dp, dv)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AZ_FUZZ_TAIL_N", "4"))))
+def test_random_generation_with_and_without_the_dense_tail_is_the_same(seed):
+    """run_selfplay with the thinned-out tail on dense request rows (az_engine_compact_rows / az_engine_advance_rows) against the
+    plain one-row-per-slot run: random slot counts (not multiples of anything), fewer or more games than slots (refill, then the
+    tail), playouts, game, fused precision, graph or eager ticks - identical records."""
+    import torch
+    from test_tail_rows_gpu import _same
+    from alphazero_openspiel_amd import engine as E
+    from alphazero_openspiel_amd.fusednet import FusedNet
+    from alphazero_openspiel_amd.network import Net
+    r = np.random.RandomState(17000 + seed)
+    name = "connect_four" if r.rand() < 0.6 else "breakthrough(rows=5,columns=4)"
+    G = int(r.randint(1024, 2700))
+    n_games = int(r.randint(G // 3, int(2.5 * G)))
+    S = int(r.randint(4, 14))
+    precision = "f16" if r.rand() < 0.5 else "f32x"
+    use_graph, tpg = bool(r.rand() < 0.7), int(r.choice([1, 4, 16]))
+    torch.manual_seed(seed)
+    eng0 = E.SelfPlayEngine(name, 8, n_playouts=2, max_games=8, device=0)
+    shape, A = eng0.game.information_state_normalized_vector_shape(), eng0.A
+    eng0.close()
+    net = Net(shape, A, n_blocks=int(r.randint(1, 4)), n_filters=int(r.choice([16, 32, 50]))).cuda().eval()
+    out = {}
+    for compact in (False, True):
+        eng = E.SelfPlayEngine(name, G, n_playouts=S, max_games=n_games, device=0, seed=1000 + seed)
+        fn = FusedNet(net, "cuda:0", max_boards=G, precision=precision)
+        prog = E.run_selfplay(eng, fn, n_games, use_graph=use_graph, ticks_per_graph=tpg, compact_tail=compact)
+        out[compact] = (eng.export(), prog)
+        eng.close()
+        fn.close()
+        assert prog["error_flags"] == 0 and prog["games_done"] == n_games, (name, G, n_games, S)
+    _same(out[False][0], out[True][0])
+    assert out[True][1]["tail_compactions"] >= 1, (G, n_games)
