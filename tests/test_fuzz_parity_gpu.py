@@ -224,3 +224,46 @@ def test_random_generation_with_and_without_the_dense_tail_is_the_same(seed):
         assert prog["error_flags"] == 0 and prog["games_done"] == n_games, (name, G, n_games, S)
     _same(out[False][0], out[True][0])
     assert out[True][1]["tail_compactions"] >= 1, (G, n_games)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AZ_FUZZ_REPLAY_N", "5"))))
+def test_random_generations_through_the_replay_store_equal_the_restatement(seed):
+    """The device replay store (train.py:156-201,226-236: FIFO of games, remove_duplicates with averaged pi / z, first-occurrence
+    order) fed by random generations - few playouts and sometimes no root noise, so positions repeat a lot; capacities that drop old
+    games; all value targets - against oracle/pyreplay.py on the same games in the reference's list format."""
+    import torch
+    from oracle import pyreplay
+    from alphazero_openspiel_amd import engine as E, games, replay
+    from alphazero_openspiel_amd.network import Net
+    r = np.random.RandomState(21000 + seed)
+    name = ["connect_four", "breakthrough(rows=5,columns=4)", "breakthrough(rows=6,columns=6)"][r.randint(3)]
+    game = games.load_game(name)
+    torch.manual_seed(int(r.randint(1 << 30)))
+    net = Net(game.information_state_normalized_vector_shape(), game.num_distinct_actions(), n_blocks=1, n_filters=16)
+    ev = E.DeviceEvaluator(net, "cuda:0")
+    per_gen = int(r.randint(3, 30))
+    cap = int(r.randint(per_gen, 3 * per_gen + 1))
+    kw = dict(n_playouts=int(r.randint(2, 9)), use_dirichlet=bool(r.rand() < 0.5),
+              backup=["on-policy", "soft-Z", "A0C", "off-policy"][r.randint(4)], temperature=float(r.choice([1.0, 0.5])))
+    rep = replay.DeviceReplay(name, max_games=cap, device=0)
+    rep.set_capacity(cap)
+    buffer = []
+    for gen in range(int(r.randint(1, 5))):
+        eng = E.SelfPlayEngine(name, int(r.randint(1, per_gen + 1)), max_games=per_gen, seed=int(r.randint(1 << 30)), **kw)
+        E.run_selfplay(eng, ev, per_gen)
+        if r.rand() < 0.5:
+            rep.append_engine(eng)
+        else:
+            rep.append_device(eng.export_device(), per_gen)
+        host_games = E.examples_from_export(game, eng.export())
+        eng.close()
+        buffer = pyreplay.fifo_append(buffer, host_games, cap)
+        want = pyreplay.remove_duplicates([s for g in buffer for s in g])
+        assert rep.dedupe() == len(want), (seed, name, kw, gen)
+        u = rep.read_unique()
+        assert [p.tolist() for p in u["pi"]] == [w[2] for w in want], (seed, gen)
+        assert u["z"].tolist() == [w[3] for w in want], (seed, gen)
+        boards = games.boards_from_bitboards(game, u["bitboards"], u["ply"])
+        assert all((boards[k] == want[k][1]).all() for k in range(len(want)))
+    rep.stats()  # raises on a device fault (key collision guard, bad index)
+    rep.close()
