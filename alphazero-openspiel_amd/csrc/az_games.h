@@ -207,7 +207,9 @@ template <int GAME> AZ_HD int az_nth_legal(const AzState &s, const AzGeom &g, in
 //   connect_four planes: 0 empty, 1 player-1 stones, 2 player-0 stones, 3 current player
 //   breakthrough planes: 0 black,  1 white,          2 empty,           3 current player
 template <int GAME> AZ_HD float az_obs_elem(const AzState &s, const AzGeom &g, int idx) {
-    int plane = idx / g.cells, cell = idx - plane * g.cells;
+    // (no run-time division: this sits at the end of every playout, on the tick kernel's critical path)
+    const int cells = GAME == AZG_CONNECT_FOUR ? 42 : g.cells;
+    int plane = (idx >= cells) + (idx >= 2 * cells) + (idx >= 3 * cells), cell = idx - plane * cells;
     if (plane == 3) return (float)(s.ply & 1);
     uint64_t bit;
     if (GAME == AZG_CONNECT_FOUR) {
