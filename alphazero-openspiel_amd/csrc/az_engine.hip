@@ -805,6 +805,13 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
     int budget = p.max_sims_per_tick;
     int next_phase = PH_RUN;
     const unsigned long long t_start = wall_clock64(); // 100 MHz
+    // The root's children, kept in registers across the playouts CHAINED in this launch (a chained playout follows a terminal
+    // hit, which expands nothing and changes only N and Q of the nodes on its path): the launch is as long as its slowest wave,
+    // and that wave is a chain - one HBM round trip less per chained playout.
+    bool rc_valid = false;
+    int rc_best = 0;
+    uint32_t rc_n = 0, rc_c0 = NONE32, rc_meta = 0;
+    double rc_q = 0.0, rc_p = 0.0;
     for (;;) {
         if (__ballot(fault != 0)) { // faults are raised per lane: make the exit wave-uniform
             next_phase = PH_IDLE;
@@ -840,7 +847,23 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
             double val = -INFINITY, cq = 0.0;
             uint32_t cn = 0, cc0 = NONE32, cmeta = 0;
             if (lane < nc) {
-                const AzNode c = t.nd[c0 + lane]; // the lane's child: two 16-byte loads
+                AzNode c;
+                if (depth == 0 && rc_valid) { // (wave-uniform) a chained playout: the root's children are still in registers
+                    c.N = rc_n;
+                    c.C0 = rc_c0;
+                    c.META = rc_meta;
+                    c.Q = rc_q;
+                    c.P = rc_p;
+                } else {
+                    c = t.nd[c0 + lane]; // the lane's child: two 16-byte loads
+                    if (depth == 0) {
+                        rc_n = c.N;
+                        rc_c0 = c.C0;
+                        rc_meta = c.META;
+                        rc_q = c.Q;
+                        rc_p = c.P;
+                    }
+                }
                 cn = c.N;
                 cc0 = c.C0;
                 cmeta = c.META;
@@ -853,6 +876,7 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
             double mx = wave_max(val);
             unsigned long long eq = __ballot(val == mx);
             int best = eq ? __ffsll(eq) - 1 : 0; // first maximum in child order (mcts.py:50)
+            if (depth == 0) rc_best = best;
             if (!eq) fault |= AZ_FAULT_BAD_PRIOR;
             if (sr.rule != AZ_SELECT_PUCT && np_ >= p.log_n) fault |= AZ_FAULT_VISIT_RANGE;
             st_children += (unsigned long long)nc;
@@ -869,6 +893,15 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
         if (term) { // mcts.py:148-152: leaf_value = -player_return(mover); update_recursive(-leaf_value)
             double x = mover == 0 ? (double)ret0 : -(double)ret0;
             backup_path<NP>(t, path, depth, x, lane);
+            { // the backed-up N and Q of the depth-1 node (lane 1 of the path registers) into the cached child record
+                const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)path.pn[0], 1);
+                const double q1 = readlane_d(path.pq[0], 1);
+                if (lane == rc_best) {
+                    rc_n = n1;
+                    rc_q = q1;
+                }
+                rc_valid = true;
+            }
             __threadfence_block();
             root_n++;
             sr.sims++;
