@@ -1277,7 +1277,7 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     // starts within the first chain_window_us of the launch (wall_clock64 ticks at 100 MHz).  Measured, connect_four
     // S=400 4096 slots: count cap 3 alone 2600 games/s; cap 6 + 10 us window 2700 (the launch lasts as long as its
     // slowest wave, ~7.5 us per chained playout; scheduling only - the games do not depend on it).
-    p.max_sims_per_tick = c.max_sims_per_tick > 0 ? c.max_sims_per_tick : 6;
+    p.max_sims_per_tick = c.max_sims_per_tick > 0 ? c.max_sims_per_tick : 10;
     p.chain_clocks = c.chain_window_us < 0 ? 0 : (c.chain_window_us > 0 ? c.chain_window_us : 10) * 100;
     p.manual_moves = c.manual_moves ? 1 : 0;
     p.arena_agent = c.arena_agent;

@@ -78,7 +78,7 @@ typedef struct az_config {
     int32_t keep_search_tree;
     int32_t backup;            /* AZ_BACKUP_* */
     int32_t rng_mode;          /* AZ_RNG_* */
-    int32_t max_sims_per_tick; /* bound on NN-free playouts (terminal hits) one slot chains per advance; 0 = default (6) */
+    int32_t max_sims_per_tick; /* bound on NN-free playouts (terminal hits) one slot chains per advance; 0 = default (10) */
     int32_t device;            /* HIP device ordinal */
     int32_t manual_moves;      /* 1: stop after each search (MCTS.search semantics); the caller reads the root and
                                   moves with az_engine_update_root — AlphaZeroBot.step outside self-play */
