@@ -1,22 +1,11 @@
 // az_head.h — fc1 + softmax + tanh of Net.forward (network.py:61-64): az_head_kernel (small action spaces),
 // az_head_logits_kernel + az_head_softmax_kernel (breakthrough's 433 / 769 outputs).
 #pragma once
-#include "az_net_common.h"
+#include "az_head_params.h"
 
 // ------------------------------------------------------------------------------------------------
 // fc1 + softmax + tanh (network.py:61-64).  One workgroup = 16 boards; the K = HW*64 reduction is split
 // over the 4 waves (k-step ks goes to wave ks & 3), partial tiles are summed through LDS.
-struct HeadParams {
-    int HW, A, n_ot, ksteps, n_boards;
-    const _Float16 *x;    // [B][HW*64]
-    const _Float16 *fc_w; // [n_ot][ksteps][64][8]
-    const _Float16 *x_lo, *fc_w_lo; // f16x3: the lo halves (scaled by 2048), same layouts
-    const float *fc_b;
-    float *priors, *values;
-};
-
-#define OTG 8
-#define HEAD_NW 8 // waves per workgroup: the K reduction is split over them (memory-bound: more loads in flight per CU)
 // X3: split-fp16 operands (see az_tower_x3_kernel): three MFMAs per product, result = acc + acc2 / 2048.
 template <bool X3> __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kernel(HeadParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -119,8 +108,6 @@ template <bool X3> __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kerne
 // cross-wave reduction; a weight fragment read from LDS feeds two MFMAs); the weight fragments of a chunk of HEAD_CK k-steps are brought into LDS ONCE per workgroup by LDS-DMA
 // (a fragment is one contiguous KiB = one wave-instruction), double buffered; A fragments come straight from the tower
 // output (each wave reads only its own boards) and are prefetched a chunk ahead.  L2 traffic for the weights drops 4x.
-#define HEAD_OTG 4  // output tiles (x16 outputs) per workgroup
-#define HEAD_RING 4 // weight chunks resident in LDS: chunk c is multiplied while c+1 .. c+RING-2 are in flight
 // HEAD_MT: board tiles (x16 boards) per wave - every weight fragment read from LDS feeds HEAD_MT MFMAs
 template <bool X3, int HEAD_MT> __global__ __launch_bounds__(256) void az_head_logits_kernel(HeadParams p, float *__restrict__ logits_g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];

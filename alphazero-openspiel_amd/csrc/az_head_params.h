@@ -1,0 +1,24 @@
+// az_head_params.h — launch parameters of the head kernels and the launcher prototypes of every kernel translation unit
+// (az_tower_f16.hip, az_tower_x3.hip, az_head.hip).  Internal; NOT part of the C ABI.
+#pragma once
+#include "az_net_common.h"
+
+struct HeadParams {
+    int HW, A, n_ot, ksteps, n_boards;
+    const _Float16 *x;    // [B][HW*64]
+    const _Float16 *fc_w; // [n_ot][ksteps][64][8]
+    const _Float16 *x_lo, *fc_w_lo; // f16x3: the lo halves (scaled by 2048), same layouts
+    const float *fc_b;
+    float *priors, *values;
+};
+
+#define OTG 8       // output tiles per pass of az_head_kernel; action spaces with more tiles take the logits + softmax kernels
+#define HEAD_NW 8   // waves per workgroup of az_head_kernel: the K reduction is split over them
+#define HEAD_OTG 4  // output tiles (x16 outputs) per workgroup of az_head_logits_kernel
+#define HEAD_RING 4 // weight chunks resident in LDS: chunk c is multiplied while c+1 .. c+RING-2 are in flight
+
+// Launchers (one per translation unit, so the kernel families compile side by side).  `device` indexes the per-device
+// "dynamic LDS attribute set" flags; every launcher returns hipGetLastError() of its launch.
+hipError_t az_launch_tower_f16(int device, int nt, int ck, int waves, int r3, const TowerParams &tp, int grid, int lds, hipStream_t st);
+hipError_t az_launch_tower_x3(int device, int nt, bool rp1, int r3, const TowerParams &tp, int grid, int lds, hipStream_t st);
+hipError_t az_launch_head(int device, bool x3, const HeadParams &hp, int n_boards, int lds_head, float *logits, hipStream_t st);

@@ -32,9 +32,7 @@
 #include "../../include/az_net.h"
 
 #include "az_net_common.h"
-#include "az_tower_f16.h"
-#include "az_tower_x3.h"
-#include "az_head.h"
+#include "az_head_params.h"
 
 // ================================================================================================
 struct az_net {
@@ -143,6 +141,9 @@ static X3Geom x3_geom(int H, int W, int r3) {
     if (g.nt < 3) g.nt = 3;
     return g;
 }
+
+// v_mfma instructions one wave (= one board) of az_tower_x3_kernel issues (az_tower_x3.h: 3 per product, every tile)
+static double x3_mfma_per_wave(int nt, int n_convs, int nks) { return 3.0 * (AZ_NET_K0STEPS + (double)(n_convs - 1) * nks) * 4 * nt; }
 
 extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     if (!desc || !out) {
@@ -344,70 +345,40 @@ extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
     return AZ_OK;
 }
 
-template <int NT, int CK, int WAVES, bool RP1, int R3> static hipError_t launch_tower_r3(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
-    static bool attr_set[AZ_MAX_DEVICES] = {false}; // the attribute is per (function, device)
-    const int dv = n->d.device;
-    if (dv < 0 || dv >= AZ_MAX_DEVICES || !attr_set[dv]) {
-        hipError_t s = hipFuncSetAttribute((const void *)az_tower_kernel<NT, CK, WAVES, RP1, R3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (s != hipSuccess) return s;
-        if (dv >= 0 && dv < AZ_MAX_DEVICES) attr_set[dv] = true;
-    }
-    hipLaunchKernelGGL((az_tower_kernel<NT, CK, WAVES, RP1, R3>), dim3(grid), dim3(WAVES * 64), lds, st, tp);
-    return hipGetLastError();
-}
-template <int NT, int CK, int WAVES, bool RP1> static hipError_t launch_tower_rp(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
-    return n->r3 == 2 ? launch_tower_r3<NT, CK, WAVES, RP1, 2>(n, tp, grid, lds, st) : launch_tower_r3<NT, CK, WAVES, RP1, 16>(n, tp, grid, lds, st);
-}
-template <int NT, int CK, int WAVES> static hipError_t launch_tower(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
-    // row-pair tiles (row stride 8), one board per wave, every tile of the wave on that board
-    if (tp.tpb && tp.bpw == 1 && tp.rs == 8 && tp.tpb <= NT) return launch_tower_rp<NT, CK, WAVES, true>(n, tp, grid, lds, st);
-    return launch_tower_rp<NT, CK, WAVES, false>(n, tp, grid, lds, st);
-}
-template <int NT> static hipError_t launch_tower_ck(const az_net *n, const TowerParams &tp, int grid, const TowerGeom &g, hipStream_t st) {
-    if constexpr (NT <= 3) { // (NT = 4 with 8 waves spills 42 registers under the 256 limit: 373 vs 351 us on 2048 8x8 boards)
-        if (g.waves == 8) return g.ck == 8 ? launch_tower<NT, 8, 8>(n, tp, grid, g.lds, st) : launch_tower<NT, 4, 8>(n, tp, grid, g.lds, st);
-    }
-    return g.ck == 8 ? launch_tower<NT, 8, 4>(n, tp, grid, g.lds, st) : launch_tower<NT, 4, 4>(n, tp, grid, g.lds, st);
+// Work partition of the f16 tower for THIS batch size.  Candidates: boards per wave x {4, 8} waves per workgroup.  One
+// workgroup per CU is resident, a launch runs in ceil(WGs / 256) rounds and a round costs ~ (2 * tiles + 1), x1.5 when two
+// waves share each SIMD: pick the candidate that minimises rounds x round cost.
+static TowerGeom choose_geom(const az_net *n, int n_boards) {
+    TowerGeom g = tower_geom(1, 4, n->d.rows, n->d.cols);
+    double best_cost = -1;
+    for (int bpw = 1; bpw <= n->bpw_max; bpw++)
+        for (int waves = 4; waves <= 8; waves += 4) {
+            TowerGeom c = tower_geom(bpw, waves, n->d.rows, n->d.cols);
+            if (c.lds > 160 * 1024 || (waves == 8 && c.nt > 3)) continue; // 8 waves need <= 256 registers each
+            long wgs = (n_boards + waves * bpw - 1) / (waves * bpw);
+            long rounds = (wgs + 255) / 256;
+            double cost = rounds * (2.0 * (c.nt < 3 ? 3 : c.nt) + 1.0) * (waves == 8 ? 1.5 : 1.0);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                g = c;
+            }
+        }
+    return g;
 }
 
-template <int NT, bool RP1, int R3> static hipError_t launch_x3_r3(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
-    static bool attr_set[AZ_MAX_DEVICES] = {false};
-    const int dv = n->d.device;
-    if (dv < 0 || dv >= AZ_MAX_DEVICES || !attr_set[dv]) {
-        hipError_t s = hipFuncSetAttribute((const void *)az_tower_x3_kernel<NT, 4, RP1, R3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (s != hipSuccess) return s;
-        if (dv >= 0 && dv < AZ_MAX_DEVICES) attr_set[dv] = true;
+extern "C" int az_net_issued_mfma_per_board(const az_net *n, int32_t n_boards, double *out) {
+    if (!n || !out || n_boards < 1) return AZ_E_INVALID;
+    const int n_convs = 2 * n->d.n_blocks, nks = n->r3 < 16 ? 15 : AZ_NET_KSTEPS;
+    const int HW = n->d.rows * n->d.cols;
+    const double head = (double)n->n_ot * (HW * AZ_NET_XOUT_C / 32) / 16.0; // one MFMA per (output tile, k-step) per 16 boards
+    if (n->precision == AZ_NET_PREC_F16X3) {
+        const X3Geom g = x3_geom(n->d.rows, n->d.cols, n->r3);
+        *out = x3_mfma_per_wave(g.nt <= 3 ? 3 : 4, n_convs, nks) + 3.0 * head; // one board per wave
+        return AZ_OK;
     }
-    hipLaunchKernelGGL((az_tower_x3_kernel<NT, 4, RP1, R3>), dim3(grid), dim3(256), lds, st, tp);
-    return hipGetLastError();
-}
-template <int NT, bool RP1> static hipError_t launch_x3(const az_net *n, const TowerParams &tp, int grid, int lds, hipStream_t st) {
-    return n->r3 == 2 ? launch_x3_r3<NT, RP1, 2>(n, tp, grid, lds, st) : launch_x3_r3<NT, RP1, 16>(n, tp, grid, lds, st);
-}
-
-template <bool X3> static int launch_head(az_net *n, const HeadParams &hp, int n_boards, hipStream_t st) {
-    if (n->n_ot > OTG) { // large action space: logits over (board tile x output-tile group), then softmax
-        constexpr int lds_logits = HEAD_RING * 4 * HEAD_OTG * 1024; // RING chunks of 16 KiB
-        const int dv = n->d.device;
-        const int col_groups = (n->n_ot + HEAD_OTG - 1) / HEAD_OTG;
-        // one board tile per wave (HEAD_MT = 1; two measured the same, tools/net_microbench.py): 64-KiB workgroups, two per CU
-        static bool lg_attr[AZ_MAX_DEVICES] = {false};
-        if (dv < 0 || dv >= AZ_MAX_DEVICES || !lg_attr[dv]) {
-            NCHK(n, hipFuncSetAttribute((const void *)az_head_logits_kernel<X3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            if (dv >= 0 && dv < AZ_MAX_DEVICES) lg_attr[dv] = true;
-        }
-        hipLaunchKernelGGL((az_head_logits_kernel<X3, 1>), dim3(((n_boards + 63) / 64 + 7) / 8 * 8 * col_groups), dim3(256), lds_logits, st, hp, n->logits);
-        hipLaunchKernelGGL(az_head_softmax_kernel<X3>, dim3((n_boards + 3) / 4), dim3(256), 0, st, hp, (const float *)n->logits);
-    } else {
-        static bool head_attr[AZ_MAX_DEVICES] = {false};
-        const int dv = n->d.device;
-        if (dv < 0 || dv >= AZ_MAX_DEVICES || !head_attr[dv]) {
-            NCHK(n, hipFuncSetAttribute((const void *)az_head_kernel<X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            if (dv >= 0 && dv < AZ_MAX_DEVICES) head_attr[dv] = true;
-        }
-        hipLaunchKernelGGL(az_head_kernel<X3>, dim3((n_boards + 15) / 16), dim3(HEAD_NW * 64), n->lds_head, st, hp);
-    }
-    NCHK(n, hipGetLastError());
+    const TowerGeom g = choose_geom(n, n_boards);
+    const int nt = g.nt < 3 ? 3 : (g.nt > 3 ? 4 : 3);
+    *out = (double)(AZ_NET_K0STEPS + (n_convs - 1) * nks) * 4 * nt / g.bpw + head;
     return AZ_OK;
 }
 
@@ -458,37 +429,15 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         tp.xout = n->xout;
         tp.xout_lo = n->xout_lo;
         const int grid = (n_boards + 3) / 4;
-        hipError_t s;
-        if (g.nt <= 3) s = g.rp1 ? launch_x3<3, true>(n, tp, grid, g.lds, st) : launch_x3<3, false>(n, tp, grid, g.lds, st);
-        else s = launch_x3<4, false>(n, tp, grid, g.lds, st);
+        hipError_t s = az_launch_tower_x3(n->d.device, g.nt, g.rp1, n->r3, tp, grid, g.lds, st);
         if (s != hipSuccess) {
             n->err = std::string("f16x3 tower launch: ") + hipGetErrorString(s);
             return AZ_E_HIP;
         }
-        return launch_head<true>(n, hp, n_boards, st);
+        NCHK(n, az_launch_head(n->d.device, true, hp, n_boards, n->lds_head, n->logits, st));
+        return AZ_OK;
     }
-    // boards per wave: one workgroup (4 waves) per CU is resident, a launch runs in ceil(WGs / 256) rounds and a
-    // round costs ~ (column tiles + fixed part): pick the bpw that minimises rounds x tiles for THIS batch size.
-    // Work partition for THIS batch size.  Candidates: boards per wave x {4, 8} waves per workgroup.  A launch runs in
-    // ceil(WGs / resident WGs) rounds; a round costs ~ (2*tiles + 1), x1.5 when two waves share each SIMD.
-    TowerGeom g = tower_geom(1, 4, n->d.rows, n->d.cols);
-    {
-        double best_cost = -1;
-        for (int bpw = 1; bpw <= n->bpw_max; bpw++)
-            for (int waves = 4; waves <= 8; waves += 4) {
-                TowerGeom c = tower_geom(bpw, waves, n->d.rows, n->d.cols);
-                if (c.lds > 160 * 1024 || (waves == 8 && c.nt > 3)) continue; // 8 waves need <= 256 registers each
-                long wgs = (n_boards + waves * bpw - 1) / (waves * bpw);
-                int per_cu = 1; // every variant's registers/LDS admit one workgroup per CU
-                long rounds = (wgs + 256 * per_cu - 1) / (256 * per_cu);
-                bool two_per_simd = waves == 8 || (per_cu == 2 && wgs > 256);
-                double cost = rounds * (2.0 * (c.nt < 3 ? 3 : c.nt) + 1.0) * (two_per_simd ? 1.5 : 1.0);
-                if (best_cost < 0 || cost < best_cost) {
-                    best_cost = cost;
-                    g = c;
-                }
-            }
-    }
+    const TowerGeom g = choose_geom(n, n_boards);
     TowerParams tp;
     tp.H = n->d.rows;
     tp.W = n->d.cols;
@@ -513,16 +462,13 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     tp.xout = n->xout;
     tp.xout_lo = nullptr;
     int per_wg = g.waves * g.bpw, grid = (n_boards + per_wg - 1) / per_wg;
-    hipError_t s;
-    switch (g.nt < 3 ? 3 : g.nt) {
-    case 3: s = launch_tower_ck<3>(n, tp, grid, g, st); break;
-    default: s = launch_tower_ck<4>(n, tp, grid, g, st); break;
-    }
+    hipError_t s = az_launch_tower_f16(n->d.device, g.nt, g.ck, g.waves, n->r3, tp, grid, g.lds, st);
     if (s != hipSuccess) {
         n->err = std::string("tower launch: ") + hipGetErrorString(s);
         return AZ_E_HIP;
     }
-    return launch_head<false>(n, hp, n_boards, st);
+    NCHK(n, az_launch_head(n->d.device, false, hp, n_boards, n->lds_head, n->logits, st));
+    return AZ_OK;
 }
 
 extern "C" int az_net_read_tower(az_net *n, float *out, int32_t n_boards) {

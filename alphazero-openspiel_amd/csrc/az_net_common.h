@@ -13,17 +13,11 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Timing-only ablation switches (make ABL="-DAZ_ABL_..."): each removes one ingredient of the tower's inner
-// structure so its cost can be read off the clock.  Outputs are wrong by construction; never shipped.
-//   AZ_ABL_NOEPI   no epilogue arithmetic / LDS writes        AZ_ABL_NOB    no B-fragment (activation) LDS reads
-//   AZ_ABL_NOA     no A-fragment (weight) LDS reads           AZ_ABL_NODMA  no weight DMA and no chunk barrier
-//   AZ_ABL_NOBARRIER  chunk barriers dropped (the DMA stays)   AZ_ABL_SKEW=n waves 4..7 start n x 64 cycles late
-//   (round 2: NOBARRIER alone and with SKEW = 30 / 60 - the two waves of a SIMD running a third / half a conv apart -
-//    all time within noise of the shipped kernel: de-phasing the wave pairs buys nothing)
 #define OCT_B 16 // one cell of one channel-octet plane: 8 fp16
 #define AZ_NET_K0STEPS 4 // k-steps of conv 0 on the device (9 taps x the one octet holding the input planes, padded to 16 groups)
 #define N_OCT 7  // 56 channels
 #define AZ_MAX_DEVICES 64
+#define X3_LOFF_RP1 (N_OCT * 96 * OCT_B) // f16x3, row-pair boards (W <= 7, H <= 6): the lo planes sit a compile-time distance after hi
 
 struct TowerParams {
     int H, W, HW, cells, cin, n_convs, n_boards, bpw;
@@ -83,29 +77,13 @@ template <int OFF> __device__ __forceinline__ void lds_read_f4_off(f32x4 &dst, u
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
 }
 __device__ __forceinline__ void keep_alive(const f32x4 &v) { asm volatile("" ::"v"(v)); }
-// (ablation stand-in for a fragment read: defines the register, touches nothing)
-__device__ __forceinline__ void fake_read128(half8 &dst, unsigned lds_byte_addr) { asm volatile("" : "=v"(dst) : "v"(lds_byte_addr)); }
-#ifdef AZ_ABL_NOA
-#define READ_A(dst, addr, off) fake_read128(dst, addr)
-#else
 #define READ_A(dst, addr, off) lds_read128_off<(off)>(dst, addr)
-#endif
 template <int OFF> __device__ __forceinline__ void lds_read32_off(unsigned &dst, unsigned lds_byte_addr) {
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
 }
-__device__ __forceinline__ void fake_read32(unsigned &dst, unsigned lds_byte_addr) { asm volatile("" : "=v"(dst) : "v"(lds_byte_addr)); }
-#ifdef AZ_ABL_NOB
-#define READ_B32_OFF(dst, addr, off) fake_read32(dst, addr)
-#else
 #define READ_B32_OFF(dst, addr, off) lds_read32_off<(off)>(dst, addr)
-#endif
-#ifdef AZ_ABL_NOB
-#define READ_B(dst, addr) fake_read128(dst, addr)
-#define READ_B_OFF(dst, addr, off) fake_read128(dst, addr)
-#else
 #define READ_B(dst, addr) lds_read128(dst, addr)
 #define READ_B_OFF(dst, addr, off) lds_read128_off<(off)>(dst, addr)
-#endif
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);

@@ -50,10 +50,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
     int (&koff)[AZ_NET_KSTEPS] = T.koff, (&ksp)[4] = T.ksp, (&koff0)[AZ_NET_K0STEPS] = T.koff0;
 
     f32x4 acc[4][NT], xres[4][NT];
-#ifdef AZ_ABL_SKEW // (timing-only) waves 4..7 start AZ_ABL_SKEW x 64 cycles late
-    if (wave >= 4)
-        for (int i = 0; i < AZ_ABL_SKEW; i++) __builtin_amdgcn_s_sleep(1);
-#endif
     // ---- prologue: a = lrelu(bn1(x0)) -> octet 0; block-1 skip conv3(x0) in fp32 -> residual stream --------
     {
         f32x4 sw[4][4]; // skip weights of this lane's 16 output channels: [mt][r] -> 4 input planes
@@ -115,11 +111,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                     std::integral_constant<int, CHUNK_B>{});
     };
     issue_bytes((const unsigned char *)p.conv_w, lds, std::integral_constant<int, C0_B>{});
-#ifndef AZ_ABL_NODMA
     if (wave == 0) // conv 0 has a single chunk: its epilogue parameters must land before that chunk's barrier
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + lane * 16),
                                          (__attribute__((address_space(3))) void *)(lds + p.off_epi), 16, 0, 0);
-#endif
 
     int chunk = 0;
     // one conv = NPARTS chunks of CKL k-steps (kf: this lane's k-group offsets) + its epilogue
@@ -140,17 +134,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
             // The weight fragments are read by untracked asm, so hipcc sees no consumer of the LDS-DMA and would NOT wait
             // for it: wait by hand.  After the barrier every wave's pieces of this chunk have landed and the other
             // buffer is free for the next chunk's DMA.
-#ifndef AZ_ABL_NODMA
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef AZ_ABL_NOBARRIER // (timing-only experiment: how much would de-phasing the two waves of a SIMD be worth?)
             __syncthreads();
-#endif
             if (chunk + 1 < n_chunks) issue_chunk(chunk + 1);
             if (!IS_FIRST && part == 0 && wave == 0) // this conv's epilogue parameters ride the same DMA path into a 2-slot ring;
                                                      // they land before the next chunk barrier, long before the epilogue reads them
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + (size_t)conv * 1024 + lane * 16),
                                                  (__attribute__((address_space(3))) void *)(lds + p.off_epi + (conv & 1) * 1024), 16, 0, 0);
-#endif
             // Fragment reads are inline asm so that the compiler neither sinks them next to their first use nor
             // inserts its own lgkmcnt(0) (left alone it waits every 8 MFMAs: 34 % MFMA utilisation).  Order:
             //   wait(all of k-step ksl) ; for each read of k-step ksl+1: {ds_read ; MFMA of ksl} ; remaining MFMAs
@@ -267,11 +257,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                 for (int nt = 0; nt < NT; nt++) {
                     f32x4 v = acc[mt][nt];
                     acc[mt][nt] = next_bias;
-#ifdef AZ_ABL_NOEPI
-                    asm volatile("" ::"v"(v));
-                    if (KIND == 2 && grow[nt] >= 0) *(half4 *)(p.xout + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = __builtin_convertvector(v, half4);
-                    continue;
-#endif
                     half4 o;
                     if (KIND == 0) {
                         o = lrelu_h4(__builtin_convertvector(v, half4));

@@ -19,7 +19,7 @@
 // k-step, a hi record followed by a lo record (both in the f16 kernel's record format); epilogues run in fp32 and split
 // their result again.  Tables, tile shapes, the 15-k-step grouping and the LDS-DMA double buffer are those of
 // az_tower_kernel above.
-#define X3_LOFF_RP1 (N_OCT * 96 * OCT_B) // row-pair boards (W <= 7, H <= 6): lo planes sit a compile-time distance after hi
+
 template <int NT, int CK, bool RP1, int R3>
 __global__ __launch_bounds__(256, 1) void az_tower_x3_kernel(TowerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];

@@ -216,7 +216,7 @@ class FusedNet:
     """Device handle: az_net_create / az_net_forward.  Call signature matches engine.DeviceEvaluator:
     evaluator(obs, priors_out, values_out)."""
 
-    def __init__(self, net, device, max_boards=4096, precision="f16"):
+    def __init__(self, net, device, max_boards=4096, precision="f32x"):
         from . import _lib
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (PRECISIONS,))
@@ -285,6 +285,18 @@ class FusedNet:
         val = torch.empty((obs.shape[0],), dtype=torch.float32, device=self.device)
         self(obs, pri, val)
         return pri, val
+
+    def issued_mfma_per_board(self, n_boards=None):
+        """v_mfma_f32_16x16x32_f16 instructions issued per board (padding included) for a launch of n_boards boards."""
+        out = C.c_double()
+        self._check(self.lib.az_net_issued_mfma_per_board(self._h, int(n_boards or self.max_boards), C.byref(out)))
+        return out.value
+
+    def kernel_label(self):
+        big = self.A + 1 > 128
+        tower = "az_tower_x3_kernel" if self.precision == "f32x" else "az_tower_kernel"
+        head = ("az_head_logits_kernel + az_head_softmax_kernel" if big else "az_head_kernel") + ("<X3>" if self.precision == "f32x" else "")
+        return tower + " + " + head
 
     def read_tower(self, n_boards):
         out = np.zeros((n_boards, self.packed["rows"] * self.packed["cols"], XOUT_C), dtype=np.float32)

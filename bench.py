@@ -22,9 +22,13 @@ Extra objects on the JSON line:
                  measured mean depth / children x sims per tick / HIP-event time of az_engine_advance
   cpu_baseline   the C oracle (same algorithm, sequential playouts, batch-1 torch CPU net — what a reference
                  worker process does) playing FULL games on the host cores: all cores, one thread, and the C1 point
-  reference_precision  the same engine and workload evaluated at the reference's precision (Net.forward is fp32,
-                 network.py:48-64) for a bounded wall time after the timed run: the fused tower's fp32-grade mode
-                 (split-fp16 operands) and, nested as torch_fp32, the torch module in fp32: games/s, sims/s, ms per forward
+  opt_in_f16     (default run: --precision f32x = the product default = the reference's fp32 Net.forward grade) the SAME
+                 engine, slots and weights with the fused tower in its opt-in fp16-operand mode, timed over whole steps
+                 through the same 16-ticks-per-graph path; and torch_fp32: the torch module in fp32 (MIOpen), wall-bounded
+  reference_precision  (only with --precision f16) the fp32-grade mode as the step-timed companion instead
+
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (a child `python -m
+torch.distributed.run`, before this process touches the GPU) and forwards rank 0's JSON line.
 """
 import argparse
 import json
@@ -42,6 +46,39 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "bf16": 2500.0,
                     "f16x3": 2500.0 / 3}  # fp32-grade mode: three fp16 MFMAs per product
+DTYPE_LABEL = {"f16x3": "f32-grade (f16x3: split-fp16 operands, 3 MFMAs per product, fp32 accumulate)"}
+PROFILE_SUMMARY = os.path.join("profiles", "r3_bench_default_pmc_summary.txt")
+
+
+def workload_key(game, G, S, blocks, filters, net, weights, precision, overlap, tpg):
+    return "|".join(str(x) for x in (game, G, S, blocks, filters, net, weights, precision, overlap, tpg))
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (tools/profile_round.sh: separate FETCH_SIZE and
+    WRITE_SIZE passes, KB per launch).  Quoted only when the summary was collected on THIS workload (its `# workload_key:`
+    line); otherwise None.  Net kernels stream 16 B per lane: FETCH_SIZE doubled (gfx950 reports wide coalesced reads at
+    half size, MI355X_MICROARCH.md); tick kernel: narrow accesses, uncalibrated, left as counted."""
+    path = os.path.join(ROOT, PROFILE_SUMMARY)
+    try:
+        lines = open(path).read().splitlines()
+    except OSError:
+        return None, None
+    if not any(ln.strip() == "# workload_key: " + key for ln in lines):
+        return None, None
+    kern, fetch, write = None, {}, {}
+    for ln in lines:
+        if ln.startswith("kernel "):
+            kern = ln[7:67].strip()
+        elif kern and ln.strip().startswith("FETCH_SIZE"):
+            fetch[kern] = 1e3 * float(ln.rsplit("=", 1)[1])
+        elif kern and ln.strip().startswith("WRITE_SIZE"):
+            write[kern] = 1e3 * float(ln.rsplit("=", 1)[1])
+    net = [k for k in fetch if "az_tower" in k or "az_head" in k]
+    tree = [k for k in fetch if "az_advance_kernel" in k]
+    if not net or not tree:
+        return None, None
+    return (sum(2 * fetch[k] + write.get(k, 0.0) for k in net), sum(fetch[k] + write.get(k, 0.0) for k in tree))
 
 
 def net_flops_per_eval(H, W, A, n_blocks, F0=50, c_in=4):
@@ -138,7 +175,8 @@ def cpu_baseline(game_name, S, n_blocks, n_filters, weight_seed, quick=False, ch
                           "seconds": c1["seconds"]},
         # BASELINE.md section 2 (build container, 8 cores, pygames stub): the real reference's multi-process path reached
         # 0.106 games/s / 1.34 k sims/s at 400 sims (8 processes), 0.91 games/s at 25 sims (1 process, 5-block checkpoint)
-        "reference_calibration": {"where": "build container, 8 cores (BASELINE.md section 2; oracle/calibrate_reference.py)",
+        "reference_calibration": {"quoted": "constants from BASELINE.md section 2, NOT measured in this run",
+                                  "where": "build container, 8 cores (BASELINE.md section 2; oracle/calibrate_reference.py)",
                                   "reference_400sims_8proc_games_per_s": 0.106, "reference_25sims_1proc_games_per_s": 0.91,
                                   # the REAL reference's in-process play_game_self (policy_fn = Net.predict, 1 thread, shipped
                                   # checkpoint) against this restatement with the same network, plies per second:
@@ -162,8 +200,11 @@ def main():
     ap.add_argument("--net", default="fused", choices=["fused", "torch"],
                     help="fused = csrc/az_net.hip MFMA tower (fp16 operands, fp32 accumulate); torch = nn.Module under PyTorch-ROCm")
     ap.add_argument("--dtype", default=None, choices=["f32", "f16", "bf16"], help="torch backend only (fused: see --precision)")
-    ap.add_argument("--precision", default="f16", choices=["f16", "f32x"],
-                    help="fused backend: f16 = fp16 MFMA operands (headline); f32x = fp32-grade split-fp16 mode (3 MFMAs per product)")
+    ap.add_argument("--precision", default="f32x", choices=["f16", "f32x"],
+                    help="fused backend: f32x = fp32-grade split-fp16 mode, 3 MFMAs per product (the product default: the reference's "
+                         "Net.forward is fp32); f16 = opt-in fp16 MFMA operands")
+    ap.add_argument("--companion-steps", type=int, default=2,
+                    help="whole steps timed for the other-precision companion leg after the main run (0 = skip)")
     ap.add_argument("--check-every", type=int, default=128)
     ap.add_argument("--nodes-per-slot", type=int, default=0, help="node-pool capacity per slot (0 = engine default)")
     ap.add_argument("--max-sims-per-tick", type=int, default=0, help="NN-free playouts a slot may chain per tick (0 = default)")
@@ -178,12 +219,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "quick", "off"],
                     help="full = SURVEY 8(d): all cores >= 64 full games + 1 thread 8 games + C1 point (~1.5 min); quick = 1 game per leg")
-    ap.add_argument("--ref-seconds", type=float, default=20.0,
-                    help="wall-time cap of the reference-precision (fp32 Net.forward) leg that follows the timed run; 0 = skip")
+    ap.add_argument("--ref-seconds", type=float, default=10.0,
+                    help="wall-time cap of the torch-fp32 (Net.forward under PyTorch-ROCm) leg that follows the timed run; 0 = skip "
+                         "both companion legs")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse several ranks on one GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: this process has not touched the GPU; start the N ranks as a CHILD process
+        # (one rank per GPU over RCCL, rendezvous on 127.0.0.1), forward rank 0's JSON line, exit with the child's code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -243,7 +297,7 @@ def main():
     # at most ~1500 games/s) - a slot that finds no game left goes idle, which would understate those legs
     n_total = (Wm + K + 2) * G
     if world == 1:
-        n_total += int(1500 * 1.5 * max(0.0, args.ref_seconds)) + G
+        n_total += (max(0, args.companion_steps) + 1) * G + int(60 * max(0.0, args.ref_seconds)) + G
     eng = E.SelfPlayEngine(game, G, n_playouts=S, max_games=n_total, device=device, seed=args.seed + 7919 * rank,
                            nodes_per_slot=args.nodes_per_slot, max_sims_per_tick=args.max_sims_per_tick,
                            chain_window_us=args.chain_window_us)
@@ -269,6 +323,7 @@ def main():
                 tick_eager()
     tick = graph.replay if graph is not None else tick_eager
     tpg = max(1, args.ticks_per_graph) if graph is not None else 1
+    tpg_main = tpg
     if args.check_every % tpg:
         raise SystemExit("--check-every must be a multiple of --ticks-per-graph")
     sync_groups = lambda: None
@@ -359,75 +414,111 @@ def main():
     e2e_tflops = evals_all / world / dt_all * f_eval / 1e12  # per GPU, over the whole timed region (gaps + tick kernel included)
     tree_gbs = sims_tick * b_sim / t_tree / 1e9
     peak = MFMA_PEAK_TFLOPS[args.dtype]
+    # MFMA work actually ISSUED (padding included) against the 2.5 PFLOP/s fp16 pipe: v_mfma_f32_16x16x32_f16 = 16384 FLOP
+    issued_mfma = evaluator.issued_mfma_per_board() if args.net == "fused" else None
+    issued_frac = (issued_mfma * 16384.0 * evals_tick / t_net / 1e12 / MFMA_PEAK_TFLOPS["f16"]) if issued_mfma else None
 
-    # HBM bytes per launch measured with rocprofv3 PMC counters on this exact command (separate FETCH_SIZE and
-    # WRITE_SIZE passes, tools/profile_round.sh -> profiles/r2_bench_default_pmc_summary.txt; KB per launch).  They cannot be collected from inside this process, so
-    # they are quoted only when the workload is the profiled one.  Net: FETCH_SIZE doubled (wide 16-B/lane streams
-    # are reported at half size on gfx950, MI355X_MICROARCH.md); tree: uncorrected (narrow accesses, uncalibrated).
+    # HBM bytes per launch: rocprofv3 PMC counters cannot be collected from inside this process, so they are read from the
+    # committed summary of the profiled command and quoted only when this run IS that workload (pmc_traffic)
     traffic_net = traffic_tree = None
-    if (game.name, G, S, args.blocks, args.filters, args.net, args.weights) == ("connect_four", 4096, 400, 10, 50,
-                                                                                "fused", "random"):
-        traffic_net = 2 * (5263e3 + 11130e3) + 21570e3 + 128e3
-        traffic_tree = 4878e3 + 5803e3
+    if args.net == "fused":
+        traffic_net, traffic_tree = pmc_traffic(workload_key(game.name, G, S, args.blocks, args.filters, args.net, args.weights,
+                                                             args.precision, args.overlap, tpg))
 
-    # ---- reference-precision legs: the SAME engine, slots, games in flight and net weights, evaluated at the reference's
-    # precision (Net.forward is fp32, network.py:48-64) for a bounded wall time each.  Games finished in the window count.
-    #   (1) the fused tower in its fp32-grade mode (AZ_NET_PREC_F16X3: split-fp16 operands, fp32 accumulation; error against
-    #       an fp64 evaluation of the order of torch-fp32's own, tests/test_fused_net.py), graph-replayed like the headline;
-    #   (2) the torch module in fp32 under PyTorch-ROCm (MIOpen), eager.
-    def precision_leg(ev, seconds, use_graph):
-        for _ in range(2):  # kernel selection / workspace allocation outside the window (and outside capture)
-            eng.advance(pri, val, obs)
-            ev(obs, pri, val)
-        torch.cuda.synchronize(device)
-        g = None
-        if use_graph:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                eng.advance(pri, val, obs)
-                ev(obs, pri, val)
-        fwd_ms = []
+    # ---- companion legs: the SAME engine, slots, games in flight and net weights under another evaluator -----------------
+    #   steps_leg  whole steps (n_steps x G games completed), the same tpg-ticks-per-graph replay path as the main run:
+    #              the fused tower at the OTHER precision (main f32x -> opt_in_f16; main f16 -> reference_precision)
+    #   wall_leg   bounded wall time, eager: the torch module in fp32 under PyTorch-ROCm (MIOpen) = what the reference's
+    #              handle_gpu would run on this device (examplegenerator.py:72-77)
+    def forward_ms(ev, n=9):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(5):
+        ms = []
+        for _ in range(n):
             e0.record()
             ev(obs, pri, val)
             e1.record()
             e1.synchronize()
-            fwd_ms.append(e0.elapsed_time(e1))
-        q0 = eng.progress()
-        tr0 = time.perf_counter()
-        n_ticks = 0
-        while time.perf_counter() - tr0 < seconds:
-            for _ in range(64 if use_graph else 8):
-                if g is not None:
-                    g.replay()
-                else:
-                    eng.advance(pri, val, obs)
-                    ev(obs, pri, val)
-                n_ticks += 1
-            torch.cuda.synchronize(device)
-        q1 = eng.progress()
-        dtr = time.perf_counter() - tr0
-        ms = float(np.median(fwd_ms))
+            ms.append(e0.elapsed_time(e1))
+        return float(np.median(ms))
+
+    def leg_result(q0, q1, dtr, n_ticks, ms):
         return {"value": (q1["games_done"] - q0["games_done"]) / dtr, "unit": "games/s",
                 "sims_per_s": (q1["sims"] - q0["sims"]) / dtr, "evals_per_s": (q1["evals"] - q0["evals"]) / dtr,
                 "games_counted": q1["games_done"] - q0["games_done"], "ticks": n_ticks, "seconds": dtr, "ms_per_launch": ms,
                 "tflops": (q1["evals"] - q0["evals"]) / max(1, n_ticks) * f_eval / (ms * 1e-3) / 1e12}
 
-    ref_prec = None
-    if world == 1 and args.net == "fused" and args.precision == "f16" and args.ref_seconds > 0:
+    def steps_leg(ev, n_steps):
+        for _ in range(2):  # workspace allocation outside capture
+            eng.advance(pri, val, obs)
+            ev(obs, pri, val)
+        torch.cuda.synchronize(device)
+        g = None
+        if not args.no_graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(tpg_main):
+                    eng.advance(pri, val, obs)
+                    ev(obs, pri, val)
+        ms = forward_ms(ev)
+        q0 = eng.progress()
+        target = q0["games_done"] + n_steps * G
+        torch.cuda.synchronize(device)
+        tr0 = time.perf_counter()
+        n_ticks = 0
+        while True:
+            for _ in range(args.check_every // tpg_main):
+                if g is not None:
+                    g.replay()
+                else:
+                    eng.advance(pri, val, obs)
+                    ev(obs, pri, val)
+            n_ticks += args.check_every
+            if eng.games_done() >= target:
+                break
+        torch.cuda.synchronize(device)
+        dtr = time.perf_counter() - tr0
+        r = leg_result(q0, eng.progress(), dtr, n_ticks, ms)
+        r.update({"steps": n_steps, "ms_per_step": 1e3 * dtr / n_steps, "ticks_per_graph": tpg_main if g is not None else 1})
+        return r
+
+    def wall_leg(ev, seconds):
+        for _ in range(2):  # kernel selection / workspace allocation outside the window
+            eng.advance(pri, val, obs)
+            ev(obs, pri, val)
+        torch.cuda.synchronize(device)
+        ms = forward_ms(ev, 5)
+        q0 = eng.progress()
+        tr0 = time.perf_counter()
+        n_ticks = 0
+        while time.perf_counter() - tr0 < seconds:
+            for _ in range(8):
+                eng.advance(pri, val, obs)
+                ev(obs, pri, val)
+                n_ticks += 1
+            torch.cuda.synchronize(device)
+        dtr = time.perf_counter() - tr0
+        return leg_result(q0, eng.progress(), dtr, n_ticks, ms)
+
+    companion = None
+    if world == 1 and args.net == "fused" and args.overlap == 1 and args.ref_seconds > 0:
         sync_groups()
-        ev_x3 = FusedNet(net.eval(), device, max_boards=G, precision="f32x")
-        ref_prec = precision_leg(ev_x3, args.ref_seconds, use_graph=not args.no_graph)
-        ref_prec.update({"dtype": "f32-grade (f16x3: every operand a pair of fp16 numbers, 3 MFMAs per product, fp32 accumulate)",
-                         "evaluator": "az_tower_x3_kernel + az_head_kernel<X3> (csrc/az_net.hip), same engine / slots / weights",
-                         "peak_tflops_f16_pipe": MFMA_PEAK_TFLOPS["f16"], "frac_of_f16_peak_issued_x3":
-                         3.0 * ref_prec["tflops"] / MFMA_PEAK_TFLOPS["f16"]})
+        other = "f16" if args.precision == "f32x" else "f32x"
+        if args.companion_steps > 0:
+            ev_o = FusedNet(net.eval(), device, max_boards=G, precision=other)
+            companion = steps_leg(ev_o, args.companion_steps)
+            odt = "f16" if other == "f16" else "f16x3"
+            companion.update({"dtype": DTYPE_LABEL.get(odt, odt), "evaluator": ev_o.kernel_label() + ", same engine / slots / weights",
+                              "peak_tflops": MFMA_PEAK_TFLOPS[odt], "frac": companion["tflops"] / MFMA_PEAK_TFLOPS[odt],
+                              "issued_mfma_per_board": ev_o.issued_mfma_per_board(),
+                              "frac_issued": ev_o.issued_mfma_per_board() * 16384.0 * (companion["tflops"] / f_eval) / MFMA_PEAK_TFLOPS["f16"]})
+            del ev_o
         ev32 = E.DeviceEvaluator(net, device, dtype=torch.float32)
-        t32 = precision_leg(ev32, min(10.0, args.ref_seconds), use_graph=False)
+        t32 = wall_leg(ev32, args.ref_seconds)
         t32.update({"dtype": "f32", "evaluator": "Net.forward fp32 under PyTorch-ROCm (MIOpen), eager",
                     "peak_tflops": MFMA_PEAK_TFLOPS["f32"]})
-        ref_prec["torch_fp32"] = t32
+        if companion is None:
+            companion = {}
+        companion["torch_fp32"] = t32
 
     if rank == 0:
         plies_per_game = moves_all / max(1.0, games_all)
@@ -435,29 +526,37 @@ def main():
             "metric": "self-play games/sec", "value": games_all / dt_all, "unit": "games/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1e3 * dt_all / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": DTYPE_LABEL.get(args.dtype, args.dtype), "data": "synthetic",
             "config": {"workload": "%s, %d sims/move, %d-block x %d-filter ResNet, %d concurrent games per GPU%s"
                                    % (game.name, S, args.blocks, args.filters, G,
                                       "" if args.overlap < 2 else " in %d slot groups on %d HIP streams" % (args.overlap, args.overlap)),
                        "overlap": args.overlap,
                        "weights": ("random-init (torch.manual_seed), eval-mode BN" if args.weights == "random" else
                                    "the reference's shipped checkpoint (5-block x 50)"), "net_backend": args.net,
-                       "net_precision": ("fp16 MFMA operands, fp32 accumulate / residual stream (ExampleGenerator: eval_precision='f16'; "
-                                         "its default is the fp32-grade 'f32x' mode timed in reference_precision)") if args.net == "fused" else args.dtype,
+                       "net_precision": (("fp32-grade: every operand a pair of fp16 numbers (hi + lo/2048), three MFMAs per product, fp32 "
+                                          "accumulate / residual stream / epilogues (ExampleGenerator default eval_precision='f32x'; the "
+                                          "reference's Net.forward is fp32, network.py:48-64)") if args.precision == "f32x" else
+                                         "fp16 MFMA operands, fp32 accumulate / residual stream (opt-in eval_precision='f16')")
+                                        if args.net == "fused" else args.dtype,
                        "tree_dtype": "f64", "c_puct": 2.5, "temperature": 1.0, "dirichlet_alpha": 0.3,
                        "parallelism": "games sharded over %d GPU(s), no collective inside the search" % world,
-                       "hip_graph": graph is not None, "ticks_per_graph": tpg},
+                       "hip_graph": graph is not None, "ticks_per_graph": tpg,
+                       "workload_key": workload_key(game.name, G, S, args.blocks, args.filters, args.net, args.weights, args.precision,
+                                                    args.overlap, tpg)},
             "sims_per_s": sims_all / dt_all, "evals_per_s": evals_all / dt_all,
             "games_timed": games_all, "ticks_timed_rank0": ticks,
             "mean_plies_per_game": plies_per_game, "mean_select_depth": d_mean, "mean_children_scanned": a_sel,
             "terminal_hit_fraction": (p1["terminal_hits"] - p0["terminal_hits"]) / max(1, sims),
             "allgather_ms": allgather_ms, "compactions": p1["compactions"] - p0["compactions"],
             "engine_hbm_gb": eng.sizes.device_bytes / 1e9,
-            "roofline": {"bound": "mfma", "kernel": ("az_tower_kernel + az_head_kernel" if args.net == "fused" else "torch Net.forward (MIOpen)")
+            "roofline": {"bound": "mfma", "kernel": (evaluator.kernel_label() if args.net == "fused" else "torch Net.forward (MIOpen)")
                                    + ", %d boards/launch" % G,
                          "achieved": net_tflops, "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
+                         "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product" if args.dtype == "f16x3" else
+                                       "dense MFMA peak for the dtype (MI355X_MICROARCH.md)"),
+                         "frac_issued": issued_frac, "issued_mfma_per_board": issued_mfma,
                          "frac_end_to_end": e2e_tflops / peak, "end_to_end_tflops": e2e_tflops,
-                         "traffic": traffic_net, "traffic_unit": "bytes/launch (PMC, profiles/r2_bench_default_pmc_summary.txt)",
+                         "traffic": traffic_net, "traffic_unit": "bytes/launch (PMC, %s)" % PROFILE_SUMMARY,
                          "flops_per_eval": f_eval, "ms_per_launch": 1e3 * t_net,
                          "batch_fill": evals_tick / G},
             "roofline_tree": {"bound": "hbm", "kernel": "az_advance_kernel (playouts + move step)",
@@ -465,8 +564,8 @@ def main():
                               "frac": tree_gbs / HBM_PEAK_GBS, "traffic": traffic_tree, "bytes_per_sim": b_sim,
                               "sims_per_launch": sims_tick, "ms_per_launch": 1e3 * t_tree},
         }
-        if ref_prec is not None:
-            out["reference_precision"] = ref_prec
+        if companion is not None:
+            out["opt_in_f16" if args.precision == "f32x" else "reference_precision"] = companion
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

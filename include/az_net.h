@@ -80,6 +80,11 @@ int az_net_reserve(az_net *n, int32_t max_boards);
  * [n_boards][H*W][64]) to a host buffer.  Synchronises the device. */
 int az_net_read_tower(az_net *n, float *out, int32_t n_boards);
 
+/* Measurement aid (bench.py's roofline.frac_issued): the number of v_mfma_f32_16x16x32_f16 instructions (16384 FLOP each,
+ * padding included) the tower + head kernels issue per board for a launch of n_boards boards, as launched by az_net_forward
+ * (the work partition depends on the batch size).  Host arithmetic only; touches no device. */
+int az_net_issued_mfma_per_board(const az_net *n, int32_t n_boards, double *out);
+
 #ifdef __cplusplus
 }
 #endif

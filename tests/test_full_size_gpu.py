@@ -30,7 +30,7 @@ def _play(n_slots, n_games, seed, keep_engine=False, **engine_kw):
     from alphazero_openspiel_amd.network import Net
     torch.manual_seed(0)
     net = Net([3, 6, 7], 7, n_blocks=10, n_filters=50).eval()
-    fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots)
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots, precision="f16")
     eng = E.SelfPlayEngine("connect_four", n_slots, n_playouts=S, max_games=n_games, seed=seed, device=0, **engine_kw)
     prog = E.run_selfplay(eng, fn, n_games, use_graph=True)
     assert prog["games_done"] == n_games and prog["error_flags"] == 0

@@ -34,7 +34,7 @@ def _play(cfg, n_slots, n_games, seed, **engine_kw):
     g = games.load_game(cfg["game"])
     torch.manual_seed(0)
     net = Net(g.information_state_normalized_vector_shape(), g.num_distinct_actions(), n_blocks=cfg["blocks"], n_filters=50).eval()
-    fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots)
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots, precision="f16")
     eng = E.SelfPlayEngine(cfg["game"], n_slots, n_playouts=cfg["S"], max_games=n_games, seed=seed, device=0, **engine_kw)
     prog = E.run_selfplay(eng, fn, n_games, use_graph=True, check_every=256)
     assert prog["games_done"] == n_games and prog["error_flags"] == 0

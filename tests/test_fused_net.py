@@ -109,7 +109,7 @@ def test_fused_forward_matches_torch(tag, n):
     boards = _random_boards(game, n, 7)
     with torch.no_grad():
         p, v = net(torch.from_numpy(boards))
-    fn = fusednet.FusedNet(net, "cuda:0", max_boards=max(n, 16))
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=max(n, 16), precision="f16")
     obs = torch.from_numpy(boards).cuda()
     pf, vf = fn.forward(obs)
     torch.cuda.synchronize()
@@ -182,7 +182,7 @@ def test_fused_outputs_do_not_depend_on_the_batch_size():
     a board's priors, value and tower output must be the same bits in all of them (the engine's slot-count invariance
     rests on this)."""
     game, net = _nets()["c4_10block"]
-    fn = fusednet.FusedNet(net, "cuda:0", max_boards=4096)
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=4096, precision="f16")
     torch.manual_seed(5)
     obs = (torch.rand(4096, 4, 6, 7, device="cuda") > 0.5).float()
     ref_p, ref_v = [t.clone() for t in fn.forward(obs)]
@@ -199,7 +199,7 @@ def test_fused_outputs_do_not_depend_on_the_batch_size():
 @pytest.mark.gpu
 def test_fused_net_rejects_bad_arguments():
     game, net = _nets()["c4_ckpt"]
-    fn = fusednet.FusedNet(net, "cuda:0", max_boards=8)
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=8, precision="f16")
     with pytest.raises(RuntimeError):
         fn.forward(torch.zeros(9, 4, 6, 7, device="cuda"))      # more boards than reserved
     with pytest.raises(RuntimeError):

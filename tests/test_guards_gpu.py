@@ -118,7 +118,7 @@ def test_engine_and_net_set_their_device_in_every_launching_call():
     from alphazero_openspiel_amd.network import Net
     torch.manual_seed(0)
     net = Net([3, 6, 7], 7, n_blocks=2, n_filters=50).eval()
-    fn = fusednet.FusedNet(net, "cuda:0", max_boards=8)
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=8, precision="f16")
     eng = E.SelfPlayEngine("connect_four", 8, n_playouts=8, max_games=8, seed=1, device=0)
     prog = E.run_selfplay(eng, fn, 8, use_graph=False)
     assert prog["games_done"] == 8 and prog["error_flags"] == 0

@@ -115,3 +115,30 @@ def test_bench_multi_gpu_branch_runs_over_rccl_in_a_one_rank_group(tmp_path):
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["allgather_ms"] is not None and line["allgather_ms"] > 0
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """The driver's own form, `python bench.py --gpus N` with no torchrun environment: the parent must start N ranks as a child
+    process and forward rank 0's JSON line (examplegenerator.py:140-162 shards inside one call).  Two ranks share the test box's
+    one GPU (gloo transport); their aggregate must be about twice one rank's on the same small workload."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    flags = ["--backend", "gloo", "--slots", "256", "--playouts", "50", "--blocks", "2", "--cpu-baseline", "off", "--ref-seconds", "0",
+             "--steps", "4", "--warmup", "1"]
+
+    def run(n):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + flags, env=env, capture_output=True,
+                             text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout[-3000:]  # rank 0 alone prints
+        return json.loads(lines[0])
+
+    two = run(2)
+    assert two["n_gpus"] == 2 and two["allgather_ms"] is not None and two["allgather_ms"] > 0
+    assert two["games_timed"] >= 2 * 4 * 256
+    one = run(1)
+    assert one["n_gpus"] == 1 and one["allgather_ms"] is None
+    # two ranks time-share ONE device here, so the aggregate cannot double; it must not collapse either (both ranks counted)
+    assert 0.6 * one["value"] < two["value"] < 2.5 * one["value"], (one["value"], two["value"])

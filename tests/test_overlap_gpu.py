@@ -20,9 +20,9 @@ def _run(game_name, n_slots, n_games, S, overlap, use_graph, blocks=2, seed=9):
     net = Net(g.information_state_normalized_vector_shape(), g.num_distinct_actions(), n_blocks=blocks, n_filters=50).eval()
     eng = E.SelfPlayEngine(game_name, n_slots, n_playouts=S, max_games=n_games, seed=seed, device=0)
     if overlap > 1:
-        ev = [fusednet.FusedNet(net, "cuda:0", max_boards=n) for _, n in E.slot_groups(n_slots, overlap)]
+        ev = [fusednet.FusedNet(net, "cuda:0", max_boards=n, precision="f16") for _, n in E.slot_groups(n_slots, overlap)]
     else:
-        ev = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots)
+        ev = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots, precision="f16")
     prog = E.run_selfplay(eng, ev, n_games, use_graph=use_graph, overlap=overlap)
     assert prog["games_done"] == n_games and prog["error_flags"] == 0
     ex = eng.export()

@@ -22,7 +22,7 @@ g = games.load_game("connect_four")
 torch.manual_seed(0)
 net = Net([3, 6, 7], 7).cuda()
 eng = E.SelfPlayEngine(g, min(a.games, 4096), n_playouts=a.playouts, max_games=a.games, seed=1)
-t = time.perf_counter(); E.run_selfplay(eng, FusedNet(net.eval(), "cuda:0", max_boards=eng.G), a.games, use_graph=True); torch.cuda.synchronize()
+t = time.perf_counter(); E.run_selfplay(eng, FusedNet(net.eval(), "cuda:0", max_boards=eng.G, precision="f16"), a.games, use_graph=True); torch.cuda.synchronize()
 t_play = time.perf_counter() - t
 rep = replay.DeviceReplay(g, max_games=a.games)
 t = time.perf_counter(); rep.append_engine(eng); torch.cuda.synchronize(); t_app = time.perf_counter() - t

@@ -27,7 +27,7 @@ reps = []
 for r in range(R):
     st = torch.cuda.Stream(dev)
     with torch.cuda.stream(st):
-        fn = fusednet.FusedNet(net, dev, max_boards=a.slots // R)
+        fn = fusednet.FusedNet(net, dev, max_boards=a.slots // R, precision="f16")
         eng = E.SelfPlayEngine("connect_four", a.slots // R, n_playouts=a.playouts, max_games=a.games // R, seed=100 + r, device=0)
         eng.reset(a.games // R)
         obs, pri, val = eng.alloc_io()

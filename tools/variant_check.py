@@ -12,7 +12,7 @@ from alphazero_openspiel_amd.network import Net  # noqa: E402
 
 torch.manual_seed(0)
 net = Net([3, 6, 7], 7, n_blocks=10, n_filters=50).eval()
-fn = FusedNet(net, "cuda:0", max_boards=4096)
+fn = FusedNet(net, "cuda:0", max_boards=4096, precision="f16")
 obs = (torch.rand(4096, 4, 6, 7, device="cuda") > 0.5).float()
 ref_p, ref_v = [t.clone() for t in fn.forward(obs)]
 torch.cuda.synchronize()
