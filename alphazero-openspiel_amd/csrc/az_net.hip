@@ -45,6 +45,7 @@ struct az_net {
     int max_boards = 0;
     int bpw_max = 0, lds_head = 0, n_ot = 0, r3 = 16;
     int precision = AZ_NET_PREC_F16;
+    bool x3b = false; // f16x3 on a row-pair board with <= 50 filters: az_tower_x3b_kernel (no output-channel tile for channels 48, 49)
 };
 static std::string g_net_err;
 
@@ -142,6 +143,86 @@ static X3Geom x3_geom(int H, int W, int r3) {
     return g;
 }
 
+// fp16 bits of conv c's weight W[co][tap][ch] in the interchange (ABI) layout: group g = tap * 7 + ch / 8, element ch % 8
+static inline uint16_t abi_weight(const uint16_t *src, int c, int co, int tap, int ch) {
+    const int g = tap * 7 + (ch >> 3), oks = g >> 2, olane = (g & 3) * 16 + (co & 15), mt = co >> 4;
+    return src[(size_t)c * AZ_NET_KSTEPS * 2048 + ((((size_t)oks * 4 + mt) * 64 + olane) * 8) + (ch & 7)];
+}
+
+// Device weight stream of az_tower_x3b_kernel (layout: struct X3B, az_net_common.h; meaning of tiles T and X: az_tower_x3b.h).
+//   conv 0:       4 k-steps x [hi mt 0..2][lo mt 0..2], then T of each k-step
+//   conv c >= 1:  part 0: k-steps 0..3 | part 1: k-steps 4..7, then T, Xhi, Xlo of k-step 6 and of k-step 7 |
+//                 part 2: k-steps 8..11 | part 3: k-steps 12..14, then T of the gather k-step
+static void build_x3b_stream(const uint16_t *hi, const uint16_t *lo, int n_convs, std::vector<unsigned char> &dev) {
+    dev.assign((size_t)X3B::C0_B + (size_t)(n_convs - 1) * X3B::CONV_B + 1024, 0);
+    // one fragment: 64 lanes x 8 fp16; f(q, l15, j) -> bits
+    auto put_frag = [&](size_t off, auto f) {
+        uint16_t *o = (uint16_t *)&dev[off];
+        for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 8; j++) o[lane * 8 + j] = f(lane >> 4, lane & 15, j);
+    };
+    // K grouping of the 15-k-step convs: group 4 ks + q < 54 = (tap, octet) = divmod(., 6); 54, 55 zero; k-step 14 = the gather
+    // k-step: element j of group q < 3 is channel 48 + (j & 1) at tap 4 q + j / 2
+    auto main_val = [&](const uint16_t *src, int c, int co, int ks, int q, int j) -> uint16_t {
+        if (c == 0) { // conv 0: group g < 9 = tap g of octet 0 (the input planes)
+            const int g = 4 * ks + q;
+            return g < 9 ? abi_weight(src, 0, co, g, j) : 0;
+        }
+        if (ks < 14) {
+            const int gp = 4 * ks + q;
+            return gp < 54 ? abi_weight(src, c, co, gp / 6, 8 * (gp % 6) + j) : 0;
+        }
+        const int tap = 4 * q + (j >> 1);
+        return (q < 3 && tap < 9) ? abi_weight(src, c, co, tap, 48 + (j & 1)) : 0;
+    };
+    auto put_record = [&](size_t off, int c, int ks) { // [hi mt 0..2][lo mt 0..2]
+        for (int part = 0; part < 2; part++)
+            for (int mt = 0; mt < 3; mt++)
+                put_frag(off + (size_t)(part * 3 + mt) * X3B::FR,
+                         [&](int q, int l, int j) { return main_val(part ? lo : hi, c, 16 * mt + l, ks, q, j); });
+    };
+    // tile T: rows 0..3 = hi 48, hi 49, lo 48, lo 49 of a shifted-B k-step (conv 0's k-steps, the gather k-step);
+    //         rows 4..7 = hi 48, hi 49, lo 48, lo 49 of the centre tap over input channels 0..47 (k-steps 6, 7)
+    auto put_t = [&](size_t off, int c, int ks) {
+        put_frag(off, [&](int q, int l, int j) -> uint16_t {
+            const bool centre = c > 0 && (ks == 6 || ks == 7);
+            const int l0 = centre ? 4 : 0;
+            if (l < l0 || l >= l0 + 4) return 0;
+            const uint16_t *src = (l - l0) < 2 ? hi : lo;
+            const int co = 48 + ((l - l0) & 1);
+            if (!centre) return main_val(src, c, co, ks, q, j);
+            const int gp = 4 * ks + q; // groups 24..29 = (tap 4, octet 0..5); 30, 31 belong to tap 5: zero rows here
+            return gp < 30 ? abi_weight(src, c, co, 4, 8 * (gp - 24) + j) : 0;
+        });
+    };
+    // tile X (k-steps 6, 7): row 2 t + cc = channel 48 + cc at tap tap_of_plane(t), over input channels 0..47, unshifted B
+    auto put_x = [&](size_t off, int c, int ks, const uint16_t *src) {
+        put_frag(off, [&](int q, int l, int j) -> uint16_t {
+            const int gp = 4 * ks + q;
+            return gp < 30 ? abi_weight(src, c, 48 + (l & 1), X3B::tap_of_plane(l >> 1), 8 * (gp - 24) + j) : 0;
+        });
+    };
+    size_t off = 0;
+    for (int ks = 0; ks < AZ_NET_K0STEPS; ks++, off += X3B::REC2) put_record(off, 0, ks);
+    for (int ks = 0; ks < AZ_NET_K0STEPS; ks++, off += X3B::FR) put_t(off, 0, ks);
+    for (int c = 1; c < n_convs; c++) {
+        const size_t base = (size_t)X3B::C0_B + (size_t)(c - 1) * X3B::CONV_B;
+        for (int part = 0; part < X3B::PARTS; part++) {
+            off = base + X3B::part_off(part);
+            const int ks0 = part * X3B::CK, ks1 = ks0 + X3B::CK < X3B::NKS ? ks0 + X3B::CK : X3B::NKS;
+            for (int ks = ks0; ks < ks1; ks++, off += X3B::REC2) put_record(off, c, ks);
+            if (part == 1)
+                for (int ks = 6; ks <= 7; ks++) {
+                    put_t(off, c, ks);
+                    put_x(off + X3B::FR, c, ks, hi);
+                    put_x(off + 2 * X3B::FR, c, ks, lo);
+                    off += 3 * X3B::FR;
+                }
+            if (part == 3) put_t(off, c, X3B::NKS - 1);
+        }
+    }
+}
+
 // v_mfma instructions one wave (= one board) of az_tower_x3_kernel issues (az_tower_x3.h: 3 per product, every tile)
 static double x3_mfma_per_wave(int nt, int n_convs, int nks) { return 3.0 * (AZ_NET_K0STEPS + (double)(n_convs - 1) * nks) * 4 * nt; }
 
@@ -177,7 +258,8 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     const int HW = d.rows * d.cols;
     if (n->precision == AZ_NET_PREC_F16X3) {
         X3Geom g = x3_geom(d.rows, d.cols, d.n_filters <= 50 ? 2 : 16);
-        if (g.nt > 4 || g.lds > 160 * 1024) {
+        n->x3b = g.rp1 && d.n_filters <= 50; // row-pair board, channels 48, 49 the only ones past three tiles
+        if (!n->x3b && (g.nt > 4 || g.lds > 160 * 1024)) {
             g_net_err = "board / filter count does not fit the f16x3 tower kernel's LDS budget";
             delete n;
             return AZ_E_INVALID;
@@ -279,6 +361,10 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
             }
         };
         std::vector<unsigned char> hi, dev;
+        if (n->x3b) {
+            build_x3b_stream(d.conv_w, d.conv_w_lo, n_convs, dev);
+            up((void **)&n->conv_w, dev.data(), dev.size());
+        } else {
         build_records((const unsigned char *)d.conv_w, hi);
         const size_t pad = 2 * 8 * 4096 + 1024; // a chunk of padding: the last (short) chunk is fetched at full length
         if (n->precision == AZ_NET_PREC_F16X3) { // per k-step: hi record, lo record
@@ -294,6 +380,7 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
             dev.resize(n_rec * rec + pad, 0);
         }
         up((void **)&n->conv_w, dev.data(), dev.size());
+        }
     }
     {   // [conv][3][64] (ABI) -> [conv][4][64] with the NEXT conv's bias in row 3 (what the kernel's ring slot holds)
         int nc = 2 * d.n_blocks;
@@ -373,7 +460,10 @@ extern "C" int az_net_issued_mfma_per_board(const az_net *n, int32_t n_boards, d
     const double head = (double)n->n_ot * (HW * AZ_NET_XOUT_C / 32) / 16.0; // one MFMA per (output tile, k-step) per 16 boards
     if (n->precision == AZ_NET_PREC_F16X3) {
         const X3Geom g = x3_geom(n->d.rows, n->d.cols, n->r3);
-        *out = x3_mfma_per_wave(g.nt <= 3 ? 3 : 4, n_convs, nks) + 3.0 * head; // one board per wave
+        if (n->x3b) // per column tile: conv 0: 4 k-steps x (27 + 2 T); then 15 x 27 + 2 x (2 T + 3 X) + 2 T (gather k-step)
+            *out = 3.0 * (AZ_NET_K0STEPS * 11 + (double)(n_convs - 1) * (15 * 9 + 2 * 5 + 2)) + 3.0 * head;
+        else
+            *out = x3_mfma_per_wave(g.nt <= 3 ? 3 : 4, n_convs, nks) + 3.0 * head; // one board per wave
         return AZ_OK;
     }
     const TowerGeom g = choose_geom(n, n_boards);
@@ -429,7 +519,8 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         tp.xout = n->xout;
         tp.xout_lo = n->xout_lo;
         const int grid = (n_boards + 3) / 4;
-        hipError_t s = az_launch_tower_x3(n->d.device, g.nt, g.rp1, n->r3, tp, grid, g.lds, st);
+        hipError_t s = n->x3b ? az_launch_tower_x3b(n->d.device, tp, grid, st)
+                              : az_launch_tower_x3(n->d.device, g.nt, g.rp1, n->r3, tp, grid, g.lds, st);
         if (s != hipSuccess) {
             n->err = std::string("f16x3 tower launch: ") + hipGetErrorString(s);
             return AZ_E_HIP;

@@ -84,6 +84,32 @@ template <int OFF> __device__ __forceinline__ void lds_read32_off(unsigned &dst,
 #define READ_B32_OFF(dst, addr, off) lds_read32_off<(off)>(dst, addr)
 #define READ_B(dst, addr) lds_read128(dst, addr)
 #define READ_B_OFF(dst, addr, off) lds_read128_off<(off)>(dst, addr)
+// Geometry of az_tower_x3b_kernel (az_tower_x3b.h): weight stream, LDS map.  Shared with the host packing in az_net.hip.
+// chunk = 4 k-steps of records (6 KiB each: hi mt 0..2, lo mt 0..2), then the extra fragments of its k-steps:
+//   part 1 (k-steps 4..7): T, Xhi, Xlo of k-step 6, then of k-step 7;  part 3 (k-steps 12..14): T of the gather k-step
+constexpr int x3b_part_bytes(int part) { return part == 1 ? 4 * 6144 + 6 * 1024 : part == 3 ? 3 * 6144 + 1024 : 4 * 6144; }
+constexpr int x3b_part_off(int part) { return part == 0 ? 0 : x3b_part_off(part - 1) + x3b_part_bytes(part - 1); }
+struct X3B {
+    static constexpr int FR = 1024;          // one A fragment: 64 lanes x 16 B
+    static constexpr int REC2 = 6 * FR;      // one k-step of tiles 0..2: hi mt 0..2, lo mt 0..2
+    static constexpr int CK = 4, NKS = 15, PARTS = 4;
+    static constexpr int part_bytes(int part) { return x3b_part_bytes(part); }
+    static constexpr int part_off(int part) { return x3b_part_off(part); }
+    static constexpr int CONV_B = x3b_part_off(3) + x3b_part_bytes(3);
+    static constexpr int C0_B = AZ_NET_K0STEPS * REC2 + AZ_NET_K0STEPS * FR; // conv 0: 4 k-steps of records + T of each
+    static constexpr int CHUNK_S = x3b_part_bytes(1);                            // LDS stride of the two chunk buffers
+    static constexpr int S_PLANE = 48 * 8, S_WAVE = 9 * S_PLANE;             // scratch: [plane][y * 8 + x][2 channels] fp32
+    static constexpr int PLANE_B = 96 * OCT_B;                               // one channel-octet plane (rcells = 96)
+    static constexpr int LO_OFF = 6 * PLANE_B + 96 * 4;                      // hi planes: 6 octets + compact plane; lo follows
+    static constexpr int OFF_EPI = 2 * CHUNK_S;
+    static constexpr int OFF_S = OFF_EPI + 2048 + 256 * 16; // epilogue ring (2 KiB) + trash slots (16 B per thread)
+    static constexpr int OFF_ACT = OFF_S + 4 * S_WAVE;
+    static constexpr int LDS = OFF_ACT + 4 * 2 * LO_OFF;
+    static constexpr int tap_of_plane(int t) { return t < 4 ? t : t + 1; } // planes 0..7 = taps 0,1,2,3,5,6,7,8 (plane 8 = tap 4)
+};
+static_assert(X3B::LDS <= 160 * 1024, "x3b LDS budget");
+static_assert(X3B::C0_B <= X3B::CHUNK_S, "conv 0 must fit a chunk buffer");
+
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);

@@ -2,6 +2,7 @@
 #include "az_head_params.h"
 #include "az_tower_f16.h" // WRec
 #include "az_tower_x3.h"
+#include "az_tower_x3b.h"
 
 template <int NT, bool RP1, int R3> static hipError_t launch_r3(int dv, const TowerParams &tp, int grid, int lds, hipStream_t st) {
     static bool attr_set[AZ_MAX_DEVICES] = {false};
@@ -19,4 +20,15 @@ template <int NT, bool RP1> static hipError_t launch(int dv, int r3, const Tower
 hipError_t az_launch_tower_x3(int device, int nt, bool rp1, int r3, const TowerParams &tp, int grid, int lds, hipStream_t st) {
     if (nt <= 3) return rp1 ? launch<3, true>(device, r3, tp, grid, lds, st) : launch<3, false>(device, r3, tp, grid, lds, st);
     return launch<4, false>(device, r3, tp, grid, lds, st);
+}
+
+hipError_t az_launch_tower_x3b(int device, const TowerParams &tp, int grid, hipStream_t st) {
+    static bool attr_set[AZ_MAX_DEVICES] = {false};
+    if (device < 0 || device >= AZ_MAX_DEVICES || !attr_set[device]) {
+        hipError_t s = hipFuncSetAttribute((const void *)az_tower_x3b_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (s != hipSuccess) return s;
+        if (device >= 0 && device < AZ_MAX_DEVICES) attr_set[device] = true;
+    }
+    hipLaunchKernelGGL((az_tower_x3b_kernel<3>), dim3(grid), dim3(256), X3B::LDS, st, tp);
+    return hipGetLastError();
 }

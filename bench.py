@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--ref-seconds", type=float, default=10.0,
                     help="wall-time cap of the torch-fp32 (Net.forward under PyTorch-ROCm) leg that follows the timed run; 0 = skip "
                          "both companion legs")
+    ap.add_argument("--tick-limit", type=int, default=0,
+                    help="profiling aid (rocprofv3 --pmc passes serialise every dispatch): end the timed region after this many ticks "
+                         "even if the K steps are not complete; the line then carries tick_limited = true and is NOT a bench result")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse several ranks on one GPU)")
@@ -348,7 +351,7 @@ def main():
                 tick()
             ticks += args.check_every
             sync_groups()
-            if eng.games_done() >= n_done:
+            if eng.games_done() >= n_done or (args.tick_limit and ticks >= args.tick_limit):
                 return eng.progress(), ticks
 
     # ---- warm-up: W steps (W*G games completed) -------------------------------------------------
@@ -544,7 +547,7 @@ def main():
                        "workload_key": workload_key(game.name, G, S, args.blocks, args.filters, args.net, args.weights, args.precision,
                                                     args.overlap, tpg)},
             "sims_per_s": sims_all / dt_all, "evals_per_s": evals_all / dt_all,
-            "games_timed": games_all, "ticks_timed_rank0": ticks,
+            "games_timed": games_all, "ticks_timed_rank0": ticks, "tick_limited": bool(args.tick_limit),
             "mean_plies_per_game": plies_per_game, "mean_select_depth": d_mean, "mean_children_scanned": a_sel,
             "terminal_hit_fraction": (p1["terminal_hits"] - p0["terminal_hits"]) / max(1, sims),
             "allgather_ms": allgather_ms, "compactions": p1["compactions"] - p0["compactions"],
