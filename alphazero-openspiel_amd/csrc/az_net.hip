@@ -154,7 +154,8 @@ static inline uint16_t abi_weight(const uint16_t *src, int c, int co, int tap, i
 //   conv c >= 1:  part 0: k-steps 0..3 | part 1: k-steps 4..7, then T, Xhi, Xlo of k-step 6 and of k-step 7 |
 //                 part 2: k-steps 8..11 | part 3: k-steps 12..14, then T of the gather k-step
 static void build_x3b_stream(const uint16_t *hi, const uint16_t *lo, int n_convs, std::vector<unsigned char> &dev) {
-    dev.assign((size_t)X3B::C0_B + (size_t)(n_convs - 1) * X3B::CONV_B + 1024, 0);
+    // (+ two chunks of zero padding: the kernel's fetch of "chunk + 2" is unconditional)
+    dev.assign((size_t)X3B::C0_B + (size_t)(n_convs - 1) * X3B::CONV_B + 2 * X3B::CONV_B, 0);
     // one fragment: 64 lanes x 8 fp16; f(q, l15, j) -> bits
     auto put_frag = [&](size_t off, auto f) {
         uint16_t *o = (uint16_t *)&dev[off];

@@ -77,6 +77,18 @@ template <int OFF> __device__ __forceinline__ void lds_read_f4_off(f32x4 &dst, u
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
 }
 __device__ __forceinline__ void keep_alive(const f32x4 &v) { asm volatile("" ::"v"(v)); }
+// An untracked asynchronous read looks "defined" to the compiler the moment it is issued, so a LONG-LIVED destination may be
+// copied (e.g. parked in an AGPR) before its data has arrived.  launder(x), placed after the s_waitcnt that covers the read,
+// makes every later use depend on an asm that runs after the wait (volatile asms keep their order).
+__device__ __forceinline__ void launder(half8 &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void launder(f32x4 &v) { asm volatile("" : "+v"(v)); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void launder(f32x2 &v) { asm volatile("" : "+v"(v)); }
+// untracked 8-byte LDS accesses (volatile asms keep their program order; LDS executes one wave's operations in order)
+template <int OFF> __device__ __forceinline__ void lds_read64_off(f32x2 &dst, unsigned lds_byte_addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_write64(unsigned lds_byte_addr, f32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(lds_byte_addr), "v"(v) : "memory"); }
 #define READ_A(dst, addr, off) lds_read128_off<(off)>(dst, addr)
 template <int OFF> __device__ __forceinline__ void lds_read32_off(unsigned &dst, unsigned lds_byte_addr) {
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));

@@ -130,201 +130,233 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
         }
     }
 
-    const int n_chunks = 1 + (p.n_convs - 1) * PARTS;
-    auto issue_bytes = [&](const unsigned char *src, unsigned char *dst, auto bytes_c) {
-        constexpr int NPIECES = decltype(bytes_c)::value / 1024;
-        static_assert(decltype(bytes_c)::value % 1024 == 0, "chunks are whole KiB pieces");
-#pragma unroll
-        for (int i = 0; i < (NPIECES + WAVES - 1) / WAVES; i++) {
-            int piece = i * WAVES + wave; // one KiB per wave-instruction, lane-linear
-            if (piece < NPIECES)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
-        }
-    };
-    // chunk c >= 1 = part (c - 1) % 4 of conv 1 + (c - 1) / 4 -> buffer c & 1
-    auto issue_part = [&](int c, auto part_c) {
+    // ---- weight stream: chunk c -> buffer c & 1 by LDS-DMA (global_load_lds, one KiB per wave-instruction).  Chunk 0 = conv 0,
+    // chunk c >= 1 = part (c - 1) % 4 of conv 1 + (c - 1) / 4.  A chunk's ONE barrier sits at the start of its LAST k-step: by
+    // then every wave holds all of the chunk's fragments in registers (its buffer is free: chunk c + 2 is fetched into it, a piece
+    // every few MFMAs), and the vmcnt(0) in front of the barrier makes chunk c + 1 - issued a whole chunk earlier - visible, so
+    // that k-step's prefetch of the NEXT k-step's fragments already reads the other buffer.  The MFMA stream therefore runs
+    // through chunk boundaries without a bubble; only the conv boundary (epilogue, then the B fragments of k-step 0) breaks it.
+    auto issue_piece = [&](int c, auto part_c, int i) { // piece 4 i + wave of chunk c (= part `part` of its conv; part -1: conv 0)
         constexpr int part = decltype(part_c)::value;
-        const int ci = (c - 1) / PARTS;
-        issue_bytes((const unsigned char *)p.conv_w + X3B::C0_B + (size_t)ci * X3B::CONV_B + X3B::part_off(part), lds + (c & 1) * CHUNK_S,
-                    std::integral_constant<int, X3B::part_bytes(part)>{});
+        constexpr int NPIECES = (part < 0 ? X3B::C0_B : X3B::part_bytes(part < 0 ? 0 : part)) / 1024;
+        // branch-free: a wave whose piece index runs past the chunk re-fetches the chunk's last piece (same bytes, same place),
+        // and a chunk index past the stream fetches its zero padding (az_net.hip)
+        int piece = i * WAVES + wave;
+        piece = piece < NPIECES ? piece : NPIECES - 1;
+        const size_t off = part < 0 ? 0 : (size_t)X3B::C0_B + (size_t)((c - 1) / PARTS) * X3B::CONV_B + X3B::part_off(part < 0 ? 0 : part);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.conv_w + off + piece * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(lds + (c & 1) * CHUNK_S + piece * 1024), 16, 0, 0);
     };
-    issue_bytes((const unsigned char *)p.conv_w, lds, std::integral_constant<int, X3B::C0_B>{});
+    constexpr int NPW = (CHUNK_S / 1024 + WAVES - 1) / WAVES; // pieces per wave of the largest chunk
+#pragma unroll
+    for (int i = 0; i < NPW; i++) issue_piece(0, std::integral_constant<int, -1>{}, i);
+#pragma unroll
+    for (int i = 0; i < NPW; i++) issue_piece(1, std::integral_constant<int, 0>{}, i);
     if (wave == 0)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + lane * 16),
                                          (__attribute__((address_space(3))) void *)(lds + X3B::OFF_EPI), 16, 0, 0);
+    half8 ah0[3], al0[3], at0; // A fragments of a conv's k-step 0: fetched during the LAST k-step of the conv before (the k-step
+                               // count is odd, so the two-deep fragment ring cannot carry them across the conv boundary)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const unsigned wb0 = lds_base + lane * 16;
+        static_for<3>([&](auto r_c) {
+            constexpr int r = decltype(r_c)::value;
+            READ_A(ah0[r], wb0, r * FR);
+            READ_A(al0[r], wb0, (3 + r) * FR);
+        });
+        READ_A(at0, wb0, AZ_NET_K0STEPS * REC2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<3>([&](auto r_c) {
+            launder(ah0[decltype(r_c)::value]);
+            launder(al0[decltype(r_c)::value]);
+        });
+        launder(at0);
+    }
 
-    int chunk = 0;
+    int chunk = 0; // the chunk of the current k-step
     auto conv_step = [&](int conv, const auto &kf, auto is_first_c) {
         constexpr bool IS_FIRST = decltype(is_first_c)::value;
-        constexpr int NPARTS = IS_FIRST ? 1 : PARTS;
         constexpr int NKSC = IS_FIRST ? AZ_NET_K0STEPS : NKS;
-        half8 ah[2][3], al[2][3], at[2], axh[2], axl[2]; // A fragments (weights): tiles 0..2 hi / lo, T, X hi / lo; double buffered
+        using K = X3BK<IS_FIRST, NT>;
+        half8 ah[2][3], al[2][3], at[2], axh[2], axl[2]; // A fragments (weights): tiles 0..2 hi / lo, T, X hi / lo; k-step ks >= 1 uses ring slot ks & 1
         half8 bh[2][NT], bl[2][NT];                      // B fragments (activations), hi / lo
         unsigned sph[NT][4], spl[NT][4];                 // gather k-step: B fragments dword by dword
         f32x4 ep_sc[4], ep_sh[4], ep_nb[4];
         const unsigned ep_base = lds_base + X3B::OFF_EPI + (conv & 1) * 1024 + q * 16;
-        static_for<NPARTS>([&](auto part_c) {
-            constexpr int part = decltype(part_c)::value;
-            constexpr int CKL = part == NPARTS - 1 ? NKSC - part * CK : CK;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const unsigned wbl = lds_base + (chunk & 1) * CHUNK_S + lane * 16;
-            using K = X3BK<IS_FIRST, NT>;
-            auto read_a = [&](auto buf_c, auto ksl_c, auto r_c) {
-                constexpr int buf = decltype(buf_c)::value, ksl = decltype(ksl_c)::value, r = decltype(r_c)::value;
-                constexpr int ks = part * CK + ksl;
-                if constexpr (r < 3) READ_A(ah[buf][r], wbl, ksl * REC2 + r * FR);
-                else if constexpr (r < 6) READ_A(al[buf][r - 3], wbl, ksl * REC2 + r * FR);
-                else {
-                    // the extra fragments sit behind the chunk's records
-                    constexpr int xbase = IS_FIRST ? AZ_NET_K0STEPS * REC2 + ks * FR
-                                                   : (part == 1 ? 4 * REC2 + (ks - 6) * 3 * FR : 3 * REC2);
-                    if constexpr (r == 6) READ_A(at[buf], wbl, xbase);
-                    else if constexpr (r == 7) READ_A(axh[buf], wbl, xbase + FR);
-                    else READ_A(axl[buf], wbl, xbase + 2 * FR);
-                }
-            };
-            auto read_b = [&](auto buf_c, auto ks_c, auto r_c) { // r in [0, n_b): plain: hi 0..NT-1, lo 0..NT-1; gather: tile-major dwords
-                constexpr int buf = decltype(buf_c)::value, ks = decltype(ks_c)::value, r = decltype(r_c)::value;
-                if constexpr (K::is_gather(ks)) {
-                    constexpr bool lo = r >= 4 * NT;
-                    constexpr int nt = (r % (4 * NT)) / 4, i = r % 4;
-                    if constexpr (lo) READ_B32_OFF(spl[nt][i], (unsigned)ksp[i], nt * 64 + LO_OFF);
-                    else READ_B32_OFF(sph[nt][i], (unsigned)ksp[i], nt * 64);
-                } else {
-                    constexpr int nt = r % NT;
-                    if constexpr (r >= NT) READ_B_OFF(bl[buf][nt], (unsigned)kf[ks], nt * 256 + LO_OFF);
-                    else READ_B_OFF(bh[buf][nt], (unsigned)kf[ks], nt * 256);
-                }
-            };
-            constexpr int ks0 = part * CK;
-            static_for<K::n_a(ks0)>([&](auto r_c) { read_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, r_c); });
-            if constexpr (part == 0) // later chunks of a conv had their B fragments fetched before the barrier
-                static_for<K::n_b(ks0)>([&](auto r_c) { read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, ks0>{}, r_c); });
-            // the other weight buffer is free now: fetch the next chunk
-            if (chunk + 1 < n_chunks) {
-                if constexpr (IS_FIRST || part == NPARTS - 1) issue_part(chunk + 1, std::integral_constant<int, 0>{});
-                else issue_part(chunk + 1, std::integral_constant<int, part + 1>{});
+        // fragment read r of k-step ks (its chunk's buffer at wb) into ring slot buf.  Order: ah 0..2, al 0..2, T, X hi, X lo
+        auto read_a = [&](unsigned wb, auto buf_c, auto ks_c, auto r_c) {
+            constexpr int buf = decltype(buf_c)::value, ks = decltype(ks_c)::value, r = decltype(r_c)::value;
+            constexpr int part = IS_FIRST ? 0 : ks / CK, ksl = ks - part * CK;
+            if constexpr (r < 3) READ_A(ah[buf][r], wb, ksl * REC2 + r * FR);
+            else if constexpr (r < 6) READ_A(al[buf][r - 3], wb, ksl * REC2 + r * FR);
+            else {
+                // the extra fragments sit behind the chunk's records
+                constexpr int xbase = IS_FIRST ? AZ_NET_K0STEPS * REC2 + ks * FR : (part == 1 ? 4 * REC2 + (ks - 6) * 3 * FR : 3 * REC2);
+                if constexpr (r == 6) READ_A(at[buf], wb, xbase);
+                else if constexpr (r == 7) READ_A(axh[buf], wb, xbase + FR);
+                else READ_A(axl[buf], wb, xbase + 2 * FR);
             }
-            if (!IS_FIRST && part == 0 && wave == 0)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + (size_t)conv * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void *)(lds + X3B::OFF_EPI + (conv & 1) * 1024), 16, 0, 0);
-            static_for<CKL>([&](auto ksl_c) {
-                constexpr int ksl = decltype(ksl_c)::value, ksg = part * CK + ksl;
-                constexpr int cur = ksl & 1, nxt = cur ^ 1;
-                constexpr bool more_here = ksl + 1 < CKL;
-                constexpr bool more_next = !more_here && part + 1 < NPARTS;
-                constexpr int ks_next = (more_here || more_next) ? ksg + 1 : 0;
-                constexpr int na_next = more_here ? K::n_a(ks_next) : 0; // a B-only prefetch across the chunk barrier skips the A reads
-                constexpr int n_next = (more_here || more_next) ? na_next + K::n_b(ks_next) : 0;
-                constexpr bool last_of_conv = !more_here && !more_next;
-                constexpr bool T_ON = K::has_t(ksg), X_ON = K::has_x(ksg), GATHER = K::is_gather(ksg);
-                constexpr int NM = 9 * NT + (T_ON ? 2 * NT : 0) + (X_ON ? 3 * NT : 0);
-                constexpr int RPS = (n_next + NM - 1) / NM > 1 ? (n_next + NM - 1) / NM : 1; // reads per MFMA slot
-                // every fragment of this k-step was issued early in the previous one (or right after the chunk barrier)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (last_of_conv)
-                    static_for<4>([&](auto mt_c) {
-                        constexpr int mt = decltype(mt_c)::value;
-                        if constexpr (!IS_FIRST) {
-                            lds_read_f4_off<256 + mt * 64>(ep_sc[mt], ep_base);
-                            lds_read_f4_off<512 + mt * 64>(ep_sh[mt], ep_base);
-                        }
-                        lds_read_f4_off<768 + mt * 64>(ep_nb[mt], ep_base);
-                    });
-                static_for<NM>([&](auto j_c) {
-                    constexpr int j = decltype(j_c)::value;
-                    static_for<RPS>([&](auto rr_c) { // reads of the next k-step, in its read order
-                        constexpr int r = RPS * j + decltype(rr_c)::value;
-                        if constexpr (r < n_next) {
-                            if constexpr (r < na_next) read_a(std::integral_constant<int, nxt>{}, std::integral_constant<int, ksl + 1>{}, std::integral_constant<int, r>{});
-                            else read_b(std::integral_constant<int, nxt>{}, std::integral_constant<int, ks_next>{}, std::integral_constant<int, r - na_next>{});
-                        }
-                    });
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    auto b_hi = [&](auto nt_c) -> half8 {
-                        constexpr int nt = decltype(nt_c)::value;
-                        if constexpr (GATHER) {
-                            const u32x4 u = {sph[nt][0], sph[nt][1], sph[nt][2], sph[nt][3]};
-                            return __builtin_bit_cast(half8, u);
-                        } else return bh[cur][nt];
-                    };
-                    auto b_lo = [&](auto nt_c) -> half8 {
-                        constexpr int nt = decltype(nt_c)::value;
-                        if constexpr (GATHER) {
-                            const u32x4 u = {spl[nt][0], spl[nt][1], spl[nt][2], spl[nt][3]};
-                            return __builtin_bit_cast(half8, u);
-                        } else return bl[cur][nt];
-                    };
-                    if constexpr (j < 9 * NT) { // tiles 0..2: pass 0 hi*hi -> acc, pass 1 hi*lo, pass 2 lo*hi -> acc2 (scaled by 2048)
-                        constexpr int pass = j / (3 * NT), nt = (j % (3 * NT)) / 3, mt = j % 3;
-                        constexpr auto ntc = std::integral_constant<int, nt>{};
-                        if constexpr (pass == 0) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][mt], b_hi(ntc), acc[mt][nt], 0, 0, 0);
-                        else if constexpr (pass == 1) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][mt], b_lo(ntc), acc2[mt][nt], 0, 0, 0);
-                        else acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][mt], b_hi(ntc), acc2[mt][nt], 0, 0, 0);
-                    } else if constexpr (T_ON && j < 11 * NT) { // tile T: x B_hi -> acc[3] (hi rows: hi*hi, lo rows: lo*hi), x B_lo -> acc2[3] (hi rows: hi*lo)
-                        constexpr int jj = j - 9 * NT, nt = jj % NT;
-                        constexpr auto ntc = std::integral_constant<int, nt>{};
-                        if constexpr (jj < NT) acc[3][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at[cur], b_hi(ntc), acc[3][nt], 0, 0, 0);
-                        else acc2[3][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at[cur], b_lo(ntc), acc2[3][nt], 0, 0, 0);
-                    } else { // tile X: hi*hi -> accxh; hi*lo, lo*hi -> accxl
-                        constexpr int jj = j - 11 * NT, nt = jj % NT;
-                        constexpr auto ntc = std::integral_constant<int, nt>{};
-                        if constexpr (jj < NT) accxh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_hi(ntc), accxh[nt], 0, 0, 0);
-                        else if constexpr (jj < 2 * NT) accxl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_lo(ntc), accxl[nt], 0, 0, 0);
-                        else accxl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axl[cur], b_hi(ntc), accxl[nt], 0, 0, 0);
+        };
+        auto read_b = [&](auto buf_c, auto ks_c, auto r_c) { // r in [0, n_b): plain: hi 0..NT-1, lo 0..NT-1; gather: tile-major dwords
+            constexpr int buf = decltype(buf_c)::value, ks = decltype(ks_c)::value, r = decltype(r_c)::value;
+            if constexpr (K::is_gather(ks)) {
+                constexpr bool lo = r >= 4 * NT;
+                constexpr int nt = (r % (4 * NT)) / 4, i = r % 4;
+                if constexpr (lo) READ_B32_OFF(spl[nt][i], (unsigned)ksp[i], nt * 64 + LO_OFF);
+                else READ_B32_OFF(sph[nt][i], (unsigned)ksp[i], nt * 64);
+            } else {
+                constexpr int nt = r % NT;
+                if constexpr (r >= NT) READ_B_OFF(bl[buf][nt], (unsigned)kf[ks], nt * 256 + LO_OFF);
+                else READ_B_OFF(bh[buf][nt], (unsigned)kf[ks], nt * 256);
+            }
+        };
+        // channels 48, 49 (az_tower_x3b.h header): tile X and the centre-tap rows of tile T are final after k-step 7, so their
+        // shifted sum through the scratch runs INSIDE the k-loop, a few instructions per MFMA slot of k-steps 8..12:
+        //   k-step 8: combine (hi, lo) accumulators, store every value at its destination position;
+        //   k-steps 9, 10, 11 (slots 9..17): read the nine tap planes of column tile 0, 1, 2 (waited for by the next k-step's lgkmcnt(0));
+        //   k-steps 10, 11, 12 (slots 0..8): sum them.  The epilogue adds the gather k-step's part (tile T rows 0..3) and finishes.
+        f32x2 s49[NT]; // (lanes q == 0) sum over the nine tap planes at this lane's position: channels 48, 49
+        f32x2 pl[9];
+        f32x4 xv;
+        f32x2 cv;
+        auto s_path = [&](auto ks_c, auto j_c) {
+            constexpr int ks = decltype(ks_c)::value, j = decltype(j_c)::value;
+            if constexpr (IS_FIRST) return;
+            if constexpr (ks == 8 && j < 9 * NT) { // 9 slots per column tile: 4 combine, 2 centre, 3 stores
+                constexpr int nt = j / 9, i = j % 9;
+                if constexpr (i < 4) xv[i] = accxh[nt][i] + accxl[nt][i] * INV_SPLIT;
+                else if constexpr (i < 6) // (lanes q == 1 hold rows 4..7 of tile T: hi c0, hi c1, lo c0, lo c1 of the centre tap)
+                    cv[i - 4] = acc[3][nt][i - 4] + (acc[3][nt][i - 2] + acc2[3][nt][i - 4]) * INV_SPLIT;
+                else if constexpr (i == 6) lds_write64(lds_base + sdst[nt][0], (f32x2){xv[0], xv[1]});
+                else if constexpr (i == 7) lds_write64(lds_base + sdst[nt][1], (f32x2){xv[2], xv[3]});
+                else lds_write64(lds_base + scen[nt], cv);
+            }
+            if constexpr (ks >= 10 && ks <= 12 && j < 9) { // the planes of tile nt, read in the k-step before, have landed (k-step start wait)
+                constexpr int nt = ks - 10, t = j;
+                if constexpr (t == 0) {
+                    static_for<9>([&](auto t_c) { launder(pl[decltype(t_c)::value]); });
+                    s49[nt] = pl[0];
+                } else s49[nt] = s49[nt] + pl[t];
+            }
+            if constexpr (ks >= 9 && ks <= 11 && j >= 9 && j < 18) { // (LDS operations of one wave execute in order: these reads see the stores)
+                constexpr int nt = ks - 9, t = j - 9;               // issued after the sums of the tile before, which still hold pl
+                lds_read64_off<t * S_PLANE + nt * 128>(pl[t], sread);
+            }
+        };
+        asm volatile("" ::: "memory"); // (the epilogue's LDS stores stay above these untracked reads)
+        static_for<K::n_b(0)>([&](auto r_c) { read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, r_c); });
+        static_for<NKSC>([&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value;
+            constexpr int part = IS_FIRST ? 0 : ks / CK, ksl = ks - part * CK;
+            constexpr int CKL = IS_FIRST ? AZ_NET_K0STEPS : (part == PARTS - 1 ? NKS - part * CK : CK);
+            constexpr bool last_of_chunk = ksl == CKL - 1, last_of_conv = ks == NKSC - 1;
+            constexpr int cur = ks & 1, nxt = cur ^ 1;
+            constexpr int na_next = last_of_conv ? 6 : K::n_a(ks + 1); // across the conv boundary: ah0 / al0 of the next conv
+            constexpr int n_next = last_of_conv ? 6 : na_next + K::n_b(ks + 1);
+            constexpr bool T_ON = K::has_t(ks), X_ON = K::has_x(ks), GATHER = K::is_gather(ks);
+            constexpr int NM = 9 * NT + (T_ON ? 2 * NT : 0) + (X_ON ? 3 * NT : 0);
+            constexpr int RPS = (n_next + NM - 1) / NM > 1 ? (n_next + NM - 1) / NM : 1; // reads per MFMA slot
+            constexpr int part2 = IS_FIRST ? 1 : (part + 2) % PARTS;                      // the part chunk + 2 is
+            static_assert(2 + 3 * (NPW - 1) < NM, "a DMA piece every third MFMA slot");
+            const unsigned wb_cur = lds_base + (chunk & 1) * CHUNK_S + lane * 16, wb_oth = lds_base + ((chunk + 1) & 1) * CHUNK_S + lane * 16;
+            const unsigned wb_next = last_of_chunk ? wb_oth : wb_cur; // where the next k-step's fragments live
+            // every fragment of this k-step was issued early in the previous one
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (last_of_chunk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (!IS_FIRST && part == 0 && wave == 0) // this conv's epilogue parameters ride the same DMA path into a 2-slot ring
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)p.epi + (size_t)conv * 1024 + lane * 16),
+                                                     (__attribute__((address_space(3))) void *)(lds + X3B::OFF_EPI + (conv & 1) * 1024), 16, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (last_of_conv)
+                static_for<4>([&](auto mt_c) {
+                    constexpr int mt = decltype(mt_c)::value;
+                    if constexpr (!IS_FIRST) {
+                        lds_read_f4_off<256 + mt * 64>(ep_sc[mt], ep_base);
+                        lds_read_f4_off<512 + mt * 64>(ep_sh[mt], ep_base);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    lds_read_f4_off<768 + mt * 64>(ep_nb[mt], ep_base);
                 });
+            static_for<NM>([&](auto j_c) {
+                constexpr int j = decltype(j_c)::value;
+                static_for<RPS>([&](auto rr_c) { // reads of the next k-step, in its read order
+                    constexpr int r = RPS * j + decltype(rr_c)::value;
+                    if constexpr (r < n_next) {
+                        if constexpr (last_of_conv) { // k-step 0 of the next conv (records start at the head of its first chunk)
+                            if constexpr (r < 3) READ_A(ah[nxt][r], wb_next, r * FR);
+                            else READ_A(al[nxt][r - 3], wb_next, r * FR);
+                        } else if constexpr (r < na_next)
+                            read_a(wb_next, std::integral_constant<int, nxt>{}, std::integral_constant<int, ks + 1>{}, std::integral_constant<int, r>{});
+                        else read_b(std::integral_constant<int, nxt>{}, std::integral_constant<int, ks + 1>{}, std::integral_constant<int, r - na_next>{});
+                    }
+                });
+                if constexpr (last_of_chunk && j >= 2 && (j - 2) % 3 == 0 && (j - 2) / 3 < NPW) // buffer chunk & 1 is free: fetch chunk + 2
+                    issue_piece(chunk + 2, std::integral_constant<int, part2>{}, (j - 2) / 3);
+                s_path(ks_c, j_c);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                auto b_hi = [&](auto nt_c) -> half8 {
+                    constexpr int nt = decltype(nt_c)::value;
+                    if constexpr (GATHER) {
+                        const u32x4 u = {sph[nt][0], sph[nt][1], sph[nt][2], sph[nt][3]};
+                        return __builtin_bit_cast(half8, u);
+                    } else return bh[cur][nt];
+                };
+                auto b_lo = [&](auto nt_c) -> half8 {
+                    constexpr int nt = decltype(nt_c)::value;
+                    if constexpr (GATHER) {
+                        const u32x4 u = {spl[nt][0], spl[nt][1], spl[nt][2], spl[nt][3]};
+                        return __builtin_bit_cast(half8, u);
+                    } else return bl[cur][nt];
+                };
+                if constexpr (j < 9 * NT) { // tiles 0..2: pass 0 hi*hi -> acc, pass 1 hi*lo, pass 2 lo*hi -> acc2 (scaled by 2048)
+                    constexpr int pass = j / (3 * NT), nt = (j % (3 * NT)) / 3, mt = j % 3;
+                    constexpr auto ntc = std::integral_constant<int, nt>{};
+                    const half8 a_hi = ks == 0 ? ah0[mt] : ah[cur][mt], a_lo = ks == 0 ? al0[mt] : al[cur][mt];
+                    if constexpr (pass == 0) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi(ntc), acc[mt][nt], 0, 0, 0);
+                    else if constexpr (pass == 1) // (the conv's first product into acc2 starts from a literal 0: no re-zeroing in the epilogue)
+                        acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo(ntc), ks == 0 ? zero4 : acc2[mt][nt], 0, 0, 0);
+                    else acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi(ntc), acc2[mt][nt], 0, 0, 0);
+                } else if constexpr (T_ON && j < 11 * NT) { // tile T: x B_hi -> acc[3] (hi rows: hi*hi, lo rows: lo*hi), x B_lo -> acc2[3] (hi rows: hi*lo)
+                    constexpr int jj = j - 9 * NT, nt = jj % NT;
+                    constexpr auto ntc = std::integral_constant<int, nt>{};
+                    const half8 a_t = ks == 0 ? at0 : at[cur];
+                    if constexpr (jj < NT) acc[3][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_t, b_hi(ntc), acc[3][nt], 0, 0, 0);
+                    else acc2[3][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_t, b_lo(ntc), ks == (IS_FIRST ? 0 : 6) ? zero4 : acc2[3][nt], 0, 0, 0);
+                } else { // tile X: hi*hi -> accxh; hi*lo, lo*hi -> accxl
+                    constexpr int jj = j - 11 * NT, nt = jj % NT;
+                    constexpr auto ntc = std::integral_constant<int, nt>{};
+                    if constexpr (jj < NT) accxh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_hi(ntc), ks == 6 ? zero4 : accxh[nt], 0, 0, 0);
+                    else if constexpr (jj < 2 * NT) accxl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_lo(ntc), ks == 6 ? zero4 : accxl[nt], 0, 0, 0);
+                    else accxl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axl[cur], b_hi(ntc), accxl[nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             });
-            chunk++;
+            if constexpr (last_of_chunk) chunk++;
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        static_for<4>([&](auto mt_c) {
+        // The next conv's k-step-0 fragments outlive the epilogue.  An untracked asynchronous read looks "defined" to the
+        // compiler the moment it is issued, so a long-lived value may be copied (e.g. parked in an AGPR) BEFORE its data has
+        // arrived: pass the ring registers through an asm placed after the wait, and only then hand them to ah0 / al0.
+        static_for<3>([&](auto r_c) {
+            constexpr int r = decltype(r_c)::value, slot = NKSC & 1; // the ring slot the last k-step prefetched into
+            launder(ah[slot][r]);
+            launder(al[slot][r]);
+            ah0[r] = ah[slot][r];
+            al0[r] = al[slot][r];
+        });
+        static_for<4>([&](auto mt_c) { // (same for the prefetched epilogue parameters)
             constexpr int mt = decltype(mt_c)::value;
             if constexpr (!IS_FIRST) {
-                keep_alive(ep_sc[mt]);
-                keep_alive(ep_sh[mt]);
+                launder(ep_sc[mt]);
+                launder(ep_sh[mt]);
             }
-            keep_alive(ep_nb[mt]);
+            launder(ep_nb[mt]);
         });
-        // ---- channels 48, 49: the shifted sum of tile X's columns through the scratch ---------------------------------
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 s49[NT]; // (lanes q == 0) sum over the nine tap planes at this lane's position: channels 48, 49
-        if constexpr (!IS_FIRST) {
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                const f32x4 xv = accxh[nt] + accxl[nt] * INV_SPLIT;
-                accxh[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                accxl[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                *(f32x2 *)(lds + sdst[nt][0]) = (f32x2){xv[0], xv[1]};
-                *(f32x2 *)(lds + sdst[nt][1]) = (f32x2){xv[2], xv[3]};
-                // centre tap (lanes q == 1 hold rows 4..7 of tile T: hi c0, hi c1, lo c0, lo c1): no shift
-                const f32x2 cv = {acc[3][nt][0] + (acc[3][nt][2] + acc2[3][nt][0]) * INV_SPLIT,
-                                  acc[3][nt][1] + (acc[3][nt][3] + acc2[3][nt][1]) * INV_SPLIT};
-                *(f32x2 *)(lds + scen[nt]) = cv;
-            }
-            // (LDS operations of one wave execute in order: the reads below see the stores above)
-            asm volatile("" ::: "memory"); // ... provided the compiler keeps the stores above the untracked reads
-            f32x2 pl[NT][9];
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int t = 0; t < 9; t++)
-                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(pl[nt][t]) : "v"(sread), "n"(t * S_PLANE + nt * 128));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                asm volatile("" : "+v"(pl[nt][0]), "+v"(pl[nt][1]), "+v"(pl[nt][2]), "+v"(pl[nt][3]), "+v"(pl[nt][4]), "+v"(pl[nt][5]),
-                             "+v"(pl[nt][6]), "+v"(pl[nt][7]), "+v"(pl[nt][8])); // consumed only after the wait above
-                f32x2 s = pl[nt][0];
-#pragma unroll
-                for (int t = 1; t < 9; t++) s = s + pl[nt][t];
-                s49[nt] = s;
-            }
-        }
         // ---- epilogue, in fp32; the result is split into (hi, lo) again ------------------------------------------
         auto epilogue = [&](auto kind) {
             constexpr int KIND = decltype(kind)::value; // 0: conv1, 1: conv2 (not last), 2: last conv
@@ -349,7 +381,6 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
                         if (q != 0) v = (f32x4){0.f, 0.f, 0.f, 0.f}; // (rows 4..15: centre-tap rows / unused)
                         acc[3][nt] = q == 0 ? (f32x4){next_bias[0], next_bias[1], 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
-                    acc2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     f32x4 o;
                     if (KIND == 0) {
                         o = __builtin_elementwise_max(v, v * 0.01f);

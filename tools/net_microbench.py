@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from alphazero_openspiel_amd import games  # noqa: E402
+from alphazero_openspiel_amd import _lib, games  # noqa: E402
 from alphazero_openspiel_amd.fusednet import FusedNet  # noqa: E402
 from alphazero_openspiel_amd.network import Net  # noqa: E402
 
@@ -22,7 +22,10 @@ ap.add_argument("--game", default="connect_four")
 ap.add_argument("--precision", default="f16", choices=["f16", "f32x"])
 ap.add_argument("--zero", action="store_true", help="zero weights and zero boards: the same instruction stream on all-zero MFMA operands "
                                                     "(DVFS check: does the chip run the identical kernel faster when it draws less power?)")
+ap.add_argument("--lib", default=None, help="an experimental build of the engine library (tools only; the product loads its own)")
 a = ap.parse_args()
+if a.lib:
+    _lib.LIB_PATH = os.path.abspath(a.lib)
 g = games.load_game(a.game)
 torch.manual_seed(0)
 net = Net(g.information_state_normalized_vector_shape(), g.num_distinct_actions(), n_blocks=a.blocks, n_filters=a.filters).eval()
