@@ -157,6 +157,7 @@ extern "C" int az_replay_stats_get(az_replay *r, az_replay_stats *out) {
     RCHK(r, hipDeviceSynchronize());
     RCHK(r, hipMemcpy(&f, r->faults, 4, hipMemcpyDeviceToHost));
     out->fault_flags = f;
+    if (f) RCHK(r, hipMemset(r->faults, 0, 4)); // reported once: the store is usable again after the caller has dealt with it
     if (f) {
         r->err = "device fault flags set:";
         if (f & AZ_REPLAY_FAULT_KEY_COLLISION) r->err += " KEY_COLLISION";
@@ -467,7 +468,10 @@ __global__ void seg_average_kernel(const long long *seg_start, long long n_seg, 
             long long pm = (head + sidx[j]) % cap;
             bad |= key2[pm] != key2[pf] || ply[pm] != ply[pf] || bb0[pm] != bb0[pf] || bb1[pm] != bb1[pf];
         }
-        if (bad) atomicOr(faults, AZ_REPLAY_FAULT_KEY_COLLISION);
+        if (__ballot(bad) != 0) { // (wave-uniform) the segment is left untouched: nothing is averaged across different histories
+            if (lane == 0) atomicOr(faults, AZ_REPLAY_FAULT_KEY_COLLISION);
+            return;
+        }
     }
     for (int a = lane; a < A; a += 64) { // flattened_buffer_dict[key][2] = [sum(x) for x in zip(acc, item[2])]
         double acc = pi[(size_t)pf * A + a];
@@ -480,6 +484,7 @@ __global__ void seg_average_kernel(const long long *seg_start, long long n_seg, 
         z[pf] = acc / (double)cnt;
     }
 }
+__global__ void clear_fault_kernel(unsigned int *faults, unsigned int mask) { atomicAnd(faults, ~mask); }
 __global__ void iota_kernel(long long *p, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i;
@@ -491,6 +496,8 @@ extern "C" int az_replay_dedupe(az_replay *r, void *stream) {
     RCHK(r, hipSetDevice(r->cfg.device));
     long long n = r->n;
     r->n_unique = 0;
+    // the collision flag describes THIS pass (an earlier one may have tripped on examples that have since been evicted)
+    hipLaunchKernelGGL(clear_fault_kernel, dim3(1), dim3(1), 0, st, r->faults, AZ_REPLAY_FAULT_KEY_COLLISION);
     if (n == 0) return AZ_OK;
     uint64_t *k_in = nullptr, *k_out = nullptr;
     long long *i_in = nullptr, *i_out = nullptr, *seg_start = nullptr, *iota = nullptr, *d_count = nullptr;

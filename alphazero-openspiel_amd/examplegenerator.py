@@ -126,9 +126,14 @@ class ExampleGenerator:
         if pairing is None and name != "test_zero_vs_zero":
             raise NotImplementedError("generate_tests supports the pairings of game_utils.py:53-145, got %s" % name)
         world, rank = azdist.world_size(), azdist.rank()
-        n_local = int(n_games / world)
+        # the reference plays int(n_games / n_pools) tests in each of its n_pools pools and divides the summed scores by
+        # 2 * n_games AS REQUESTED (examplegenerator.py:149,189): same count (same rule as _play_and_gather) and same divisor
+        if world == 1:
+            n_local = int(n_games / self.n_pools) * self.n_pools if self.n_pools > 1 else int(n_games)
+        else:
+            n_local = int(n_games / world)
         if n_local < 1:
-            raise ValueError("n_games=%d is fewer than the %d ranks" % (n_games, world))
+            raise ValueError("n_games=%d is fewer than the %d ranks / pools" % (n_games, max(world, self.n_pools)))
         if world > 1:
             self.net = self.net.to(self.device)
             azdist.broadcast_net(self.net, src=0)
@@ -160,7 +165,7 @@ class ExampleGenerator:
         self._generation += 1
         total = torch.tensor([float(s1.sum() + s2.sum()), float(2 * n_local)], dtype=torch.float64)
         total = azdist.all_reduce_sum(total, self.device)
-        avg_reward = float(total[0] / total[1])
+        avg_reward = float(total[0]) / (2 * n_games)  # examplegenerator.py:189: sum(examples) / (2 * n_games)
         if self.generate_statistics:  # examplegenerator.py:192-193 (this rank's tests)
             return avg_reward, statistics
         return avg_reward

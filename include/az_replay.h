@@ -46,7 +46,7 @@ typedef struct az_replay_stats {
     int64_t n_games, n_examples; /* currently stored */
     int64_t n_unique;            /* after the last az_replay_dedupe (0 before) */
     int64_t games_dropped;       /* total FIFO evictions */
-    int64_t fault_flags;         /* AZ_REPLAY_FAULT_* raised on the device since create */
+    int64_t fault_flags;         /* AZ_REPLAY_FAULT_* raised on the device since the last az_replay_stats_get (reading clears them) */
 } az_replay_stats;
 
 #define AZ_REPLAY_FAULT_KEY_COLLISION 1u /* remove_duplicates met two different histories with one 64-bit key */
@@ -88,7 +88,9 @@ int az_replay_dedupe(az_replay *r, void *stream);
 int az_replay_sample(az_replay *r, const int64_t *indices, int32_t batch, uint64_t seed, float *x, float *pi,
                      float *z, void *stream);
 
-/* Counters and device fault flags; synchronises the device.  Returns AZ_E_DEVICE when a fault flag is set. */
+/* Counters and device fault flags; synchronises the device.  Returns AZ_E_DEVICE when a fault flag is set; the flags are
+ * reported ONCE (cleared by this call).  az_replay_dedupe clears AZ_REPLAY_FAULT_KEY_COLLISION when it starts, leaves a group
+ * whose members differ untouched (nothing is averaged across different histories) and returns AZ_E_DEVICE for that pass. */
 int az_replay_stats_get(az_replay *r, az_replay_stats *out);
 
 /* Debug/parity read-back of the de-duplicated list (host arrays; any may be NULL): key hash, pi [n][A] float64,

@@ -77,6 +77,11 @@ def test_generate_tests_and_the_reference_pairings():
     assert -1.0 <= avg_net <= 1.0
     with pytest.raises(NotImplementedError):
         gen.generate_tests(4, lambda *a, **k: None, 10)
+    # n_pools > 1: int(n_games / n_pools) * n_pools tests are played, the sum is divided by 2 * n_games as requested
+    # (examplegenerator.py:149,189) - 16 tests over 3 pools = 15 tests = 30 games; a net that always loses would score -30/32
+    gen3 = ExampleGenerator(net, "connect_four", torch.device("cuda:0"), is_test=True, n_pools=3, n_processes=1, seed=4)
+    avg3 = gen3.generate_tests(16, game_utils.test_net_vs_random, 0)
+    assert gen3.last_progress["games_done"] == 30 and abs(avg3 * 32 - round(avg3 * 32)) < 1e-9 and abs(avg3) <= 30 / 32
     out = game_utils.test_zero_vs_mcts(net.predict, 30, "connect_four", n_playouts=20, c_puct=2.5)
     assert len(out) == 3 and out[2] is None and out[0] in (-1.0, 0.0, 1.0) and out[1] in (-1.0, 0.0, 1.0)
     out = game_utils.test_net_vs_random(net.predict, "connect_four")

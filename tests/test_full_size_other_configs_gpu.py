@@ -28,13 +28,13 @@ CONFIGS = {
 }
 
 
-def _play(cfg, n_slots, n_games, seed, **engine_kw):
+def _play(cfg, n_slots, n_games, seed, precision="f16", **engine_kw):
     from alphazero_openspiel_amd import engine as E, fusednet
     from alphazero_openspiel_amd.network import Net
     g = games.load_game(cfg["game"])
     torch.manual_seed(0)
     net = Net(g.information_state_normalized_vector_shape(), g.num_distinct_actions(), n_blocks=cfg["blocks"], n_filters=50).eval()
-    fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots, precision="f16")
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots, precision=precision)
     eng = E.SelfPlayEngine(cfg["game"], n_slots, n_playouts=cfg["S"], max_games=n_games, seed=seed, device=0, **engine_kw)
     prog = E.run_selfplay(eng, fn, n_games, use_graph=True, check_every=256)
     assert prog["games_done"] == n_games and prog["error_flags"] == 0
@@ -56,10 +56,12 @@ def _same_records(ex, ex_b, n):
     assert (ex["child_action"][:n][live_child] == ex_b["child_action"][:n][live_child]).all()
 
 
-@pytest.fixture(scope="module", params=["C3", "C5"])
+# both evaluator precisions: "f32x" is the product default (fp32-grade, the reference's Net.forward precision), "f16" the opt-in
+@pytest.fixture(scope="module", params=["C3-f16", "C5-f16", "C3-f32x", "C5-f32x"])
 def full_run(request):
-    cfg = CONFIGS[request.param]
-    ex, prog = _play(cfg, cfg["G"], cfg["G"], seed=77)
+    tag, precision = request.param.split("-")
+    cfg = dict(CONFIGS[tag], precision=precision)
+    ex, prog = _play(cfg, cfg["G"], cfg["G"], seed=77, precision=precision)
     return request.param, cfg, ex, prog
 
 
@@ -92,12 +94,14 @@ def test_games_obey_the_rules_and_conserve_visits(full_run):
 def test_records_do_not_depend_on_the_number_of_slots(full_run):
     tag, cfg, ex, prog = full_run
     n = cfg["n_small"]
-    ex_b, prog_b = _play(cfg, n // 2, n, seed=77)   # half as many slots as games: every slot is refilled once
+    ex_b, prog_b = _play(cfg, n // 2, n, seed=77, precision=cfg["precision"])   # half as many slots as games: every slot is refilled once
     _same_records(ex, ex_b, n)
 
 
 def test_thousands_of_compactions_leave_the_records_unchanged(full_run):
     tag, cfg, ex, prog = full_run
+    if cfg["precision"] != "f16":
+        pytest.skip("compaction is independent of the evaluator; run once per config")
     n = cfg["n_small"]
     maxc = games.load_game(cfg["game"]).max_children()
     small = 3 * (cfg["S"] + 1) * maxc + 64   # room for three searches: re-rooting compacts every second or third move

@@ -95,6 +95,8 @@ def test_replay_sample_flags_out_of_range_indices():
     assert not torch.isnan(x[0]).any() and not torch.isnan(x[3]).any()
     with pytest.raises(RuntimeError, match="BAD_INDEX"):
         rep.stats()
+    assert rep.stats()["fault_flags"] == 0   # reported once: the store recovers from a bad caller index
+    assert rep.dedupe() == n
     rep.close()
 
 
@@ -107,7 +109,19 @@ def test_dedupe_refuses_to_merge_different_histories_that_share_a_key():
     assert rep.lib.az_replay_debug_set_key(rep._h, 1, int(u["key"][0])) == 0
     with pytest.raises(RuntimeError, match="different histories"):
         rep.dedupe()
+    # the refused pass averaged NOTHING across the two histories, and the flag does not stick: with the key restored the
+    # next pass succeeds and gives what two plain passes give on an untouched store (a pass writes its averages back into
+    # the first occurrence, train.py:156-201, so the second pass is not a no-op - but the refused one must have been)
+    assert rep.lib.az_replay_debug_set_key(rep._h, 1, int(u["key"][u["buffer_index"].tolist().index(1)])) == 0
+    assert rep.dedupe() == n
+    u2 = rep.read_unique()
+    assert rep.stats()["fault_flags"] == 0
     rep.close()
+    ctrl = _small_replay()
+    assert ctrl.dedupe() == n and ctrl.dedupe() == n
+    uc = ctrl.read_unique()
+    assert (u2["key"] == uc["key"]).all() and (u2["pi"] == uc["pi"]).all() and (u2["z"] == uc["z"]).all()
+    ctrl.close()
     assert n > 1
 
 
