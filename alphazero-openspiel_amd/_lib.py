@@ -28,13 +28,13 @@ class AzConfig(C.Structure):
                 ("arena_agent", C.c_int32), ("arena_opponent", C.c_int32), ("opponent_sims", C.c_int32),
                 ("arena_flip", C.c_int32), ("opponent_uct_c", C.c_double),
                 ("select_rule", C.c_int32), ("arena_probabilistic", C.c_int32),
-                ("num_probabilistic_actions", C.c_int32), ("reserved0", C.c_int32)]
+                ("num_probabilistic_actions", C.c_int32), ("spare_pools", C.c_int32)]
 
 
 class AzSizes(C.Structure):
     _fields_ = [("num_actions", C.c_int32), ("obs_planes", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("max_children", C.c_int32), ("max_plies", C.c_int32), ("n_slots", C.c_int32),
-                ("reserved", C.c_int32), ("nodes_per_slot", C.c_int64), ("max_games", C.c_int64),
+                ("spare_pools", C.c_int32), ("nodes_per_slot", C.c_int64), ("max_games", C.c_int64),
                 ("device_bytes", C.c_int64)]
 
 

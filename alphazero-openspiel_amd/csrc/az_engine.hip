@@ -10,14 +10,14 @@
 // reference's Python-float arithmetic: given the same (priors, value) inputs and the same random
 // draws, visit counts and Q values are bit-identical to mcts.py.
 //
-// HBM layout: node pools of 32-byte records (AzNode, az_engine_internal.h), index = (slot*2 + half)*cap + node:
+// HBM layout: node pools of 32-byte records (AzNode, az_engine_internal.h), index = pool*cap + node:
 //   N   u32   visit count                       Q  f64  mean value (viewpoint of the player who moved in)
 //   C0  u32   index of first child              P  f64  prior
 //   META u32  action (low 16) | n_children<<16  (children are contiguous, ascending action = dict insertion order of
 //                                                mcts.py:62-64)
 // so one select level is ONE contiguous read of nodes [c0 .. c0+n) by lanes 0..n-1 (two 16-byte loads per lane).
-// Each slot has two pool halves; re-rooting compacts the kept subtree into the other half
-// (Cheney copy, breadth-first) when the free tail could not hold another search.
+// A slot owns one pool; re-rooting compacts the kept subtree into a spare pool taken from a shared set and gives the
+// old pool back (Cheney copy, breadth-first) when the free tail could not hold another search.
 // One launch per tick (az_advance_kernel): the agent's move step is the cold prologue of the slot's next tick.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -204,9 +204,9 @@ __device__ double np_sum_sparse(const PwPlan &pw, double v, int act, int nc) {
 struct Pool {
     AzNode *nd;
 };
-__device__ __forceinline__ Pool pool_at(const Params &p, int g, int half) {
-    size_t base = ((size_t)g * 2 + half) * p.cap;
-    Pool q = {p.nodes + base};
+#define POOL_MASK 0x3FFFFFFF // which[g] = pool id | select rule << 30
+__device__ __forceinline__ Pool pool_at(const Params &p, int pool) {
+    Pool q = {p.nodes + (size_t)pool * p.cap};
     return q;
 }
 __device__ __forceinline__ void pool_init_root(const Pool &t, int lane) {
@@ -334,7 +334,7 @@ __device__ uint32_t compact_subtree(const Pool &a, const Pool &b, uint32_t root,
 // ------------------------------------------------------------------------------------------------
 // Slot registers shared by the kernels
 struct SlotRegs {
-    int gid, sims, half;
+    int gid, sims, pool;
     int rule; // AZ_SELECT_* of the slot's current tree (the reference's Node.use_puct, uniform within a tree)
     uint32_t root, alloc;
     AzState rs;
@@ -345,9 +345,9 @@ __device__ __forceinline__ void slot_load(const Params &p, int g, SlotRegs &r) {
     r.rs.bb1 = rfl64(p.bb1[g]);
     r.rs.ply = rfl(p.ply[g]);
     r.sims = rfl(p.sims[g]);
-    r.half = rfl(p.which[g]);
-    r.rule = r.half >> 1;
-    r.half &= 1;
+    r.pool = rfl(p.which[g]);
+    r.rule = (r.pool >> 30) & 1;
+    r.pool &= POOL_MASK;
     r.root = rflu(p.root[g]);
     r.alloc = rflu(p.alloc[g]);
 }
@@ -358,7 +358,7 @@ __device__ __forceinline__ void slot_store(const Params &p, int g, const SlotReg
     p.bb1[g] = r.rs.bb1;
     p.ply[g] = r.rs.ply;
     p.sims[g] = r.sims;
-    p.which[g] = r.half | (r.rule << 1);
+    p.which[g] = r.pool | (r.rule << 30);
     p.root[g] = r.root;
     p.alloc[g] = r.alloc;
 }
@@ -402,10 +402,34 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, b
     }
     sr.root = c0 + (uint32_t)sel;
     if (sr.alloc + p.need_per_move > p.cap) {
-        Pool o = pool_at(p, g, sr.half ^ 1);
+        // take a spare pool: entry k of spare[] holds a free pool id or -1.  Every taker hands a pool back (its old one, into
+        // the entry it emptied) as soon as its copy is done, so a waiting wave only waits for copies in progress.
+        int k = -1, np = -1;
+        if (lane == 0) {
+            int kk = g % p.n_spare;
+            for (int spin = 0; spin < (1 << 22); spin++) {
+                int v = atomicExch(&p.spare[kk], -1);
+                if (v >= 0) {
+                    k = kk;
+                    np = v;
+                    break;
+                }
+                kk = kk + 1 == p.n_spare ? 0 : kk + 1;
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        k = __shfl(k, 0);
+        np = __shfl(np, 0);
+        if (np < 0) { // (no copy finished within ~a second: cannot happen unless the device is wedged)
+            fault |= AZ_FAULT_POOL_EXHAUSTED;
+            return;
+        }
+        Pool o = pool_at(p, np);
         sr.alloc = compact_subtree(t, o, sr.root, lane);
+        // (every load from the old pool has returned - its data went into the stores above - so the pool can change hands)
+        if (lane == 0) atomicExch(&p.spare[k], sr.pool);
         sr.root = 0;
-        sr.half ^= 1;
+        sr.pool = np;
         t = o;
         st_compact++;
         if (sr.alloc + p.need_per_move > p.cap) fault |= AZ_FAULT_POOL_EXHAUSTED;
@@ -460,7 +484,7 @@ template <int GAME>
 __device__ __forceinline__ void move_step(const Params &p, const int g, const int lane, int ph, SlotRegs sr,
                                           float *__restrict__ obs_row) { // obs_row: this slot's row of the request buffer
     const AzGeom &geom = p.geom;
-    Pool t = pool_at(p, g, sr.half);
+    Pool t = pool_at(p, sr.pool);
     unsigned long long st_moves = 0, st_evals = 0, st_compact = 0;
     unsigned int fault = 0;
 
@@ -688,7 +712,7 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
     if (ph != PH_RUN && ph != PH_WAIT_LEAF && ph != PH_WAIT_ROOT) return;
 
     const AzGeom &geom = p.geom;
-    Pool t = pool_at(p, g, sr.half);
+    Pool t = pool_at(p, sr.pool);
     unsigned long long st_sims = 0, st_evals = 0, st_term = 0, st_depth = 0, st_children = 0, st_nodes = 0;
     unsigned int fault = 0;
     Path<NP> path;
@@ -1073,7 +1097,7 @@ __global__ __launch_bounds__(256) void az_update_root_kernel(Params p, const int
     if (action < 0 || ph == PH_IDLE) return;
     SlotRegs sr;
     slot_load(p, g, sr);
-    Pool t = pool_at(p, g, sr.half);
+    Pool t = pool_at(p, sr.pool);
     unsigned int fault = 0;
     unsigned long long st_compact = 0;
     { // the action must be legal in the root state (apply_action on an illegal move would corrupt the bitboards)
@@ -1119,13 +1143,14 @@ __global__ void az_reset_kernel(Params p) {
     p.bb1[g] = p.start.bb1;
     p.ply[g] = p.start.ply;
     p.sims[g] = 0;
-    p.which[g] = (!p.keep_tree || p.manual_moves ? AZ_SELECT_PUCT
-                  : (p.start.ply >= (p.arena_agent == AZ_ARENA_SELF_PLAY ? 1 : 2) ? p.select_rule : AZ_SELECT_PUCT)) << 1; // start_rule
+    p.which[g] = g | (!p.keep_tree || p.manual_moves ? AZ_SELECT_PUCT
+                      : (p.start.ply >= (p.arena_agent == AZ_ARENA_SELF_PLAY ? 1 : 2) ? p.select_rule : AZ_SELECT_PUCT)) << 30; // pool g, start_rule
+    for (int k = g; k < p.n_spare; k += p.G) p.spare[k] = p.G + k; // the spare pools follow the slots' own
     p.root[g] = 0;
     p.alloc[g] = 1;
     p.depth[g] = 0;
     p.leaf_node[g] = 0;
-    size_t base = (size_t)g * 2 * p.cap;
+    size_t base = (size_t)g * p.cap;
     AzNode root0 = {0u, NONE32, 0u, 0u, 0.0, 0.0};
     p.nodes[base] = root0;
     for (int i = 0; i < ST_N; i++) p.stats[(size_t)g * ST_N + i] = 0;
@@ -1228,11 +1253,11 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
                        "rng_mode PHILOX, manual_moves 0)";
         return AZ_E_INVALID;
     }
-    if ((c.select_rule != AZ_SELECT_PUCT && c.select_rule != AZ_SELECT_UCT) || c.reserved0 != 0 ||
+    if ((c.select_rule != AZ_SELECT_PUCT && c.select_rule != AZ_SELECT_UCT) || c.spare_pools < 0 ||
         (c.arena_probabilistic != 0 && c.arena_probabilistic != 1) ||
         (c.arena_probabilistic && c.arena_agent != AZ_ARENA_ZERO)) {
         g_create_err = "select_rule must be AZ_SELECT_PUCT or AZ_SELECT_UCT; arena_probabilistic 0/1 (AZ_ARENA_ZERO only); "
-                       "reserved0 must be 0";
+                       "spare_pools >= 0";
         return AZ_E_INVALID;
     }
     if (!c.use_dirichlet && c.n_playouts < 2 && c.arena_agent != AZ_ARENA_NET) {
@@ -1291,12 +1316,17 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     // compacts; every compaction is a ~100-400 us single-wave Cheney copy that holds the whole launch), capped so that the
     // pools take at most half of the free HBM.  Measured, connect_four S=400, 4096 slots: 6 searches 10k compactions per
     // 4096 games, 24 searches 820, whole game none: +1.7 % games/s over 24, 31 GB instead of 18 GB.
+    // Spare pools (round 3): a slot owns ONE pool; the target of a compaction comes from a shared set of spare pools (default
+    // n_slots / 16, at least 16, at most n_slots) instead of a private second half per slot - the same capacity per slot in
+    // half the memory (connect_four S=400, 4096 slots: 31 -> 16.5 GB; breakthrough 6x6 S=800: 155 -> 82 GB).
+    p.n_spare = c.spare_pools > 0 ? c.spare_pools : (c.n_slots / 16 > 16 ? c.n_slots / 16 : 16);
+    if (p.n_spare > c.n_slots) p.n_spare = c.n_slots;
     int64_t moves_room = p.max_plies < 48 ? p.max_plies : 48;
     int64_t cap = c.nodes_per_slot > 0 ? c.nodes_per_slot : moves_room * p.need_per_move + 64;
     if (c.nodes_per_slot <= 0) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            int64_t fit = (int64_t)(free_b / 2 / ((size_t)c.n_slots * 2 * sizeof(AzNode)));
+            int64_t fit = (int64_t)(free_b / 2 / ((size_t)(c.n_slots + p.n_spare) * sizeof(AzNode)));
             int64_t floor_cap = (int64_t)3 * p.need_per_move + 64;
             if (cap > fit) cap = fit > floor_cap ? fit : floor_cap;
         }
@@ -1326,13 +1356,15 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     z.max_plies = p.max_plies;
     z.n_slots = p.G;
     z.nodes_per_slot = cap;
+    z.spare_pools = p.n_spare;
     z.max_games = c.max_games;
 
-    size_t nodes = (size_t)p.G * 2 * p.cap, G = (size_t)p.G;
+    size_t nodes = ((size_t)p.G + p.n_spare) * p.cap, G = (size_t)p.G;
     size_t plies = (size_t)c.max_games * p.max_plies;
     int rc = AZ_OK;
 #define DA(ptr, n) if (rc == AZ_OK) rc = dalloc(e, &(ptr), (n))
     DA(p.nodes, nodes);
+    DA(p.spare, (size_t)p.n_spare);
     DA(p.row_slot, G); DA(p.req_row, G); DA(p.n_rows_live, 1);
     DA(p.phase, G); DA(p.gid, G); DA(p.ply, G); DA(p.sims, G); DA(p.which, G); DA(p.depth, G); DA(p.leaf_ply, G);
     DA(p.root, G); DA(p.alloc, G); DA(p.leaf_node, G); DA(p.path, G * p.pstride);
@@ -1855,12 +1887,12 @@ extern "C" int az_engine_read_root(az_engine *e, int32_t slot, int64_t *root_n, 
     if (!e || slot < 0 || slot >= e->p.G) return AZ_E_INVALID;
     HIPCHK(e, hipSetDevice(e->cfg.device));
     HIPCHK(e, hipDeviceSynchronize());
-    int half = 0;
+    int pool = 0;
     uint32_t root = 0, n = 0, c0 = 0, meta = 0;
-    HIPCHK(e, hipMemcpy(&half, e->p.which + slot, sizeof half, hipMemcpyDeviceToHost));
-    half &= 1; // bit 1 = the tree's select rule
+    HIPCHK(e, hipMemcpy(&pool, e->p.which + slot, sizeof pool, hipMemcpyDeviceToHost));
+    pool &= POOL_MASK; // bit 30 = the tree's select rule
     HIPCHK(e, hipMemcpy(&root, e->p.root + slot, sizeof root, hipMemcpyDeviceToHost));
-    size_t base = ((size_t)slot * 2 + half) * e->p.cap;
+    size_t base = (size_t)pool * e->p.cap;
     double q = 0;
     AzNode rn;
     HIPCHK(e, hipMemcpy(&rn, e->p.nodes + base + root, sizeof rn, hipMemcpyDeviceToHost));
@@ -1891,17 +1923,17 @@ extern "C" int64_t az_engine_read_tree(az_engine *e, int32_t slot, int64_t max_n
     if (!e || slot < 0 || slot >= e->p.G || max_nodes < 0) return AZ_E_INVALID;
     HIPCHK(e, hipSetDevice(e->cfg.device));
     HIPCHK(e, hipDeviceSynchronize());
-    int half = 0;
+    int pool = 0;
     uint32_t root = 0, alloc = 0;
-    HIPCHK(e, hipMemcpy(&half, e->p.which + slot, sizeof half, hipMemcpyDeviceToHost));
-    half &= 1; // bit 1 = the tree's select rule
+    HIPCHK(e, hipMemcpy(&pool, e->p.which + slot, sizeof pool, hipMemcpyDeviceToHost));
+    pool &= POOL_MASK; // bit 30 = the tree's select rule
     HIPCHK(e, hipMemcpy(&root, e->p.root + slot, sizeof root, hipMemcpyDeviceToHost));
     HIPCHK(e, hipMemcpy(&alloc, e->p.alloc + slot, sizeof alloc, hipMemcpyDeviceToHost));
     if (alloc > e->p.cap || root >= alloc) {
         e->err = "corrupt slot";
         return AZ_E_DEVICE;
     }
-    size_t base = ((size_t)slot * 2 + half) * e->p.cap;
+    size_t base = (size_t)pool * e->p.cap;
     std::vector<AzNode> nd_all(alloc);
     HIPCHK(e, hipMemcpy(nd_all.data(), e->p.nodes + base, sizeof(AzNode) * (size_t)alloc, hipMemcpyDeviceToHost));
     std::vector<uint32_t> N(alloc), C0(alloc), M(alloc);

@@ -43,8 +43,12 @@ struct Params {
     long long n_games, max_games;
     AzState start;
     PwPlan pw;
-    // node pools (array of structures: a child block is one contiguous run of 32-byte nodes)
+    // node pools (array of structures: a child block is one contiguous run of 32-byte nodes): G + n_spare pools of `cap` nodes.
+    // A slot OWNS one pool (which[g] & POOL_MASK); a compaction copies the kept subtree into a spare pool taken from
+    // spare[] (entry = pool id, -1 = taken) and hands the old pool back through the same entry.
     AzNode *nodes;
+    int n_spare;
+    int *spare;
     // per slot
     int *phase, *gid, *ply, *sims, *which, *depth, *leaf_ply;
     uint32_t *root, *alloc, *leaf_node, *path;

@@ -37,7 +37,7 @@ class SelfPlayEngine:
                  use_dirichlet=True, keep_search_tree=True, backup="on-policy", max_games=None, device=0,
                  rng="philox", seed=0, nodes_per_slot=0, max_sims_per_tick=0, chain_window_us=0, manual_moves=False,
                  dirichlet_alpha=0.3, arena_agent=None, opponent=None, opponent_sims=0, opponent_uct_c=1.0, arena_flip=False,
-                 use_puct=True, use_probabilistic_actions=False, num_probabilistic_actions=1000):
+                 use_puct=True, use_probabilistic_actions=False, num_probabilistic_actions=1000, spare_pools=0):
         self.lib = _lib.load()
         self.game = Game(game_name) if isinstance(game_name, str) else game_name
         self.device_index = _device_index(device)
@@ -58,6 +58,7 @@ class SelfPlayEngine:
         cfg.device = self.device_index
         cfg.manual_moves = int(bool(manual_moves))
         cfg.nodes_per_slot = int(nodes_per_slot)
+        cfg.spare_pools = int(spare_pools)  # 0 = default (n_slots / 16, at least 16)
         cfg.max_games = int(max_games if max_games is not None else n_slots)
         cfg.c_puct = float(c_puct)
         cfg.dirichlet_ratio = float(dirichlet_ratio)

@@ -109,7 +109,9 @@ typedef struct az_config {
     /* num_probabilistic_actions (alphazerobot.py:36,81-85): a sampling agent (self-play, or arena_probabilistic) samples
      * only while fewer than this many moves have been played, then plays the argmax.  0 = the reference's default, 1000; < 0 = never sample. */
     int32_t num_probabilistic_actions;
-    int32_t reserved0; /* 0 */
+    /* node pools shared as compaction targets (a slot owns one pool of nodes_per_slot nodes; re-rooting copies the kept
+     * subtree into a spare pool when the pool cannot hold another search): 0 = default (n_slots / 16, at least 16) */
+    int32_t spare_pools;
 } az_config;
 
 #define AZ_SELECT_PUCT 0 /* Q + c_puct * P * sqrt(N_parent) / (N + 1)                         mcts.py:78 */
@@ -135,7 +137,7 @@ typedef struct az_sizes {
     int32_t max_children; /* upper bound on legal actions of any state */
     int32_t max_plies;    /* upper bound on game length */
     int32_t n_slots;
-    int32_t reserved;
+    int32_t spare_pools;  /* pools beyond the slots' own: (n_slots + spare_pools) * nodes_per_slot nodes are allocated */
     int64_t nodes_per_slot;
     int64_t max_games;
     int64_t device_bytes; /* HBM held by the engine */
