@@ -473,6 +473,16 @@ extern "C" int az_net_issued_mfma_per_board(const az_net *n, int32_t n_boards, d
     return AZ_OK;
 }
 
+extern "C" const char *az_net_kernel_label(const az_net *n) {
+    if (!n) return "";
+    const bool big = n->n_ot > OTG;
+    if (n->precision == AZ_NET_PREC_F16X3) {
+        if (n->x3b) return big ? "az_tower_x3b_kernel + az_head_logits_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3b_kernel + az_head_kernel<X3>";
+        return big ? "az_tower_x3_kernel + az_head_logits_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3_kernel + az_head_kernel<X3>";
+    }
+    return big ? "az_tower_kernel + az_head_logits_kernel + az_head_softmax_kernel" : "az_tower_kernel + az_head_kernel";
+}
+
 extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float *values, int32_t n_boards, void *stream) {
     if (!n || !obs || !priors || !values || n_boards < 1) return AZ_E_INVALID;
     if (n_boards > n->max_boards) {

@@ -293,10 +293,7 @@ class FusedNet:
         return out.value
 
     def kernel_label(self):
-        big = self.A + 1 > 128
-        tower = "az_tower_x3_kernel" if self.precision == "f32x" else "az_tower_kernel"
-        head = ("az_head_logits_kernel + az_head_softmax_kernel" if big else "az_head_kernel") + ("<X3>" if self.precision == "f32x" else "")
-        return tower + " + " + head
+        return self.lib.az_net_kernel_label(self._h).decode()
 
     def read_tower(self, n_boards):
         out = np.zeros((n_boards, self.packed["rows"] * self.packed["cols"], XOUT_C), dtype=np.float32)
