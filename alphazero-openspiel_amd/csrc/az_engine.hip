@@ -390,7 +390,7 @@ __device__ __forceinline__ void backup_path(const Pool &t, Path<NP> &path, int d
 // mcts.py:64): MCTS.__init__'s root is always PUCT (mcts.py:122), a leaf root replaced by update_root takes MCTS.use_puct
 // (mcts.py:199-200) - so the caller says which of the two the reference would have built at this point.
 __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, bool drop, int fresh_rule, int lane,
-                       unsigned int &fault, unsigned long long &st_compact) {
+                       unsigned int &fault, unsigned long long &st_compact, int rsv_k = -1, int rsv_np = -1) {
     uint32_t c0 = rflu(t.nd[sr.root].C0);
     if (drop || sel < 0 || c0 == NONE32) {
         sr.rule = fresh_rule;
@@ -402,10 +402,11 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, b
     }
     sr.root = c0 + (uint32_t)sel;
     if (sr.alloc + p.need_per_move > p.cap) {
-        // take a spare pool: entry k of spare[] holds a free pool id or -1.  Every taker hands a pool back (its old one, into
-        // the entry it emptied) as soon as its copy is done, so a waiting wave only waits for copies in progress.
-        int k = -1, np = -1;
-        if (lane == 0) {
+        // the target is a spare pool: entry k of spare[] holds a free pool id or -1.  In a launch with deferred compaction the
+        // caller has RESERVED one before it changed anything (move_step); otherwise take one here - every taker hands a pool
+        // back (its old one, into the entry it emptied) as soon as its copy is done, so a waiting wave waits for copies in progress.
+        int k = rsv_k, np = rsv_np;
+        if (np < 0 && lane == 0) {
             int kk = g % p.n_spare;
             for (int spin = 0; spin < (1 << 22); spin++) {
                 int v = atomicExch(&p.spare[kk], -1);
@@ -424,6 +425,23 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, b
             fault |= AZ_FAULT_POOL_EXHAUSTED;
             return;
         }
+        st_compact++;
+        if (rsv_np >= 0) {
+            // queue the copy for az_compact_kernel (it runs right after this kernel, a workgroup per job, and writes alloc[g]);
+            // nothing in the rest of this tick touches the tree, and the next tick finds it at node 0 of the new pool
+            if (lane == 0) {
+                const int j = atomicAdd(p.cjob_count, 1);
+                p.cjob_list[j] = g;
+                p.cj_from[g] = sr.pool;
+                p.cj_entry[g] = k;
+                p.cj_root[g] = sr.root;
+            }
+            sr.root = 0;
+            sr.pool = np;
+            sr.alloc = p.cap; // (placeholder: az_compact_kernel stores the live count)
+            t = pool_at(p, np);
+            return;
+        }
         Pool o = pool_at(p, np);
         sr.alloc = compact_subtree(t, o, sr.root, lane);
         // (every load from the old pool has returned - its data went into the stores above - so the pool can change hands)
@@ -431,8 +449,83 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, b
         sr.root = 0;
         sr.pool = np;
         t = o;
-        st_compact++;
         if (sr.alloc + p.need_per_move > p.cap) fault |= AZ_FAULT_POOL_EXHAUSTED;
+    }
+}
+
+// Deferred compaction: one 256-thread workgroup per queued slot copies the subtree under cj_root[g] of pool cj_from[g] into the
+// slot's new pool, breadth first, 256 parents per round: the children of a round are numbered by a block-wide prefix sum (the
+// SAME order - hence the same node indices - as compact_subtree's wave-wide one) and copied one node per thread and step,
+// so a round is two or three memory round trips whatever the fan-out.  The last workgroup to finish clears the queue.
+#define CJ_THREADS 256
+#define AZ_COMPACT_WGS 64 // workgroups of az_compact_kernel (jobs are rare; a burst is worked off 64 at a time)
+__global__ __launch_bounds__(CJ_THREADS) void az_compact_kernel(Params p) {
+    __shared__ uint32_t sh_off[CJ_THREADS + 1], sh_c0[CJ_THREADS];
+    __shared__ int sh_wave[CJ_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_jobs = p.cjob_count[0];
+    for (int job = blockIdx.x; job < n_jobs; job += gridDim.x) {
+        const int g = p.cjob_list[job];
+        const Pool a = pool_at(p, p.cj_from[g]), b = pool_at(p, p.which[g] & POOL_MASK);
+        if (tid == 0) b.nd[0] = a.nd[p.cj_root[g]]; // C0 is still an OLD index until scanned
+        __threadfence_block();
+        __syncthreads();
+        uint32_t s = 0, f = 1;
+        while (s < f) {
+            const uint32_t cnt = f - s < CJ_THREADS ? f - s : CJ_THREADS;
+            uint32_t oc0 = NONE32;
+            int nch = 0;
+            if ((uint32_t)tid < cnt) {
+                oc0 = b.nd[s + tid].C0;
+                nch = oc0 == NONE32 ? 0 : (int)(b.nd[s + tid].META >> 16);
+            }
+            int incl = wave_incl_scan(nch, lane);
+            if (lane == 63) sh_wave[wv] = incl;
+            __syncthreads();
+            int base = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < CJ_THREADS / 64; w++) {
+                if (w < wv) base += sh_wave[w];
+                total += sh_wave[w];
+            }
+            const uint32_t off = (uint32_t)(base + incl - nch); // exclusive prefix: this parent's first child among the round's
+            sh_off[tid] = off;
+            sh_c0[tid] = oc0;
+            if (tid == CJ_THREADS - 1) sh_off[CJ_THREADS] = (uint32_t)total;
+            if (nch > 0) b.nd[s + tid].C0 = f + off;
+            __syncthreads();
+            // child c of the round (0 <= c < total) belongs to the last parent whose prefix is <= c
+            for (uint32_t c = (uint32_t)tid; c < (uint32_t)total; c += CJ_THREADS) {
+                int lo = 0, hi = CJ_THREADS - 1; // largest i with sh_off[i] <= c and a non-empty range
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (sh_off[mid] <= c) lo = mid;
+                    else hi = mid - 1;
+                }
+                const uint4 *src = (const uint4 *)(a.nd + sh_c0[lo] + (c - sh_off[lo]));
+                uint4 *dst = (uint4 *)(b.nd + f + c);
+                const uint4 w0 = src[0], w1 = src[1];
+                dst[0] = w0;
+                dst[1] = w1;
+            }
+            __threadfence_block(); // the next round reads what this one wrote (same workgroup, global memory)
+            __syncthreads();
+            f += (uint32_t)total;
+            s += cnt;
+        }
+        if (tid == 0) {
+            p.alloc[g] = f;
+            atomicExch(&p.spare[p.cj_entry[g]], p.cj_from[g]); // the old pool changes hands
+            if (f + p.need_per_move > p.cap) atomicOr(p.faults, AZ_FAULT_POOL_EXHAUSTED);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(p.cjob_count + 1, 1) == (int)gridDim.x - 1) { // every workgroup has read n_jobs and finished its jobs
+            p.cjob_count[0] = 0;
+            p.cjob_count[1] = 0;
+        }
     }
 }
 
@@ -487,6 +580,31 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
     Pool t = pool_at(p, sr.pool);
     unsigned long long st_moves = 0, st_evals = 0, st_compact = 0;
     unsigned int fault = 0;
+    // Deferred compaction (az_compact_kernel): if this move may have to compact, RESERVE the spare pool before anything is
+    // changed; a slot that finds none free (they are all with jobs queued in this launch) simply returns - its phase and state
+    // are untouched, it repeats the move step next tick, after the queued copies have handed their pools back.
+    int rsv_k = -1, rsv_np = -1;
+    if (p.defer_compact && p.keep_tree && !p.manual_moves && (ph == PH_MOVE || ph == PH_OPP_DONE) && sr.alloc + p.need_per_move > p.cap) {
+        if (lane == 0) {
+            int kk = g % p.n_spare;
+            for (int i = 0; i < (p.n_spare < 64 ? p.n_spare : 64); i++) {
+                int v = atomicExch(&p.spare[kk], -1);
+                if (v >= 0) {
+                    rsv_k = kk;
+                    rsv_np = v;
+                    break;
+                }
+                kk = kk + 1 == p.n_spare ? 0 : kk + 1;
+            }
+        }
+        rsv_k = __shfl(rsv_k, 0);
+        rsv_np = __shfl(rsv_np, 0);
+        if (rsv_np < 0) return;
+    }
+    auto release_rsv = [&]() { // (paths that leave the move step early hand an unused reservation back)
+        if (rsv_np >= 0 && lane == 0) atomicExch(&p.spare[rsv_k], rsv_np);
+        rsv_np = -1;
+    };
 
     if (ph == PH_OPP_DONE) { // arena: apply the move the opponent bot chose; the agent's tree follows it (alphazerobot.py:60-64)
         const int action = rfl(p.opp_action[g]);
@@ -510,12 +628,16 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         if (fault) {
             ph = PH_IDLE;
         } else if (term) {
-            if (!finish_game_take_next(p, g, lane, sr, ret0, 0)) return;
+            if (!finish_game_take_next(p, g, lane, sr, ret0, 0)) {
+                release_rsv();
+                return;
+            }
             reroot(p, g, sr, t, -1, true, start_rule(p), lane, fault, st_compact);
             ph = opponent_to_move(p, sr.gid, sr.rs) ? PH_OPPONENT : (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN);
         } else { // a leaf root here = the agent's first step of the game: update_root runs only with >= 2 moves played
             reroot(p, g, sr, t, sel, !p.keep_tree, (p.keep_tree && sr.rs.ply >= 2) ? p.select_rule : AZ_SELECT_PUCT, lane, fault,
-                   st_compact);
+                   st_compact, rsv_k, rsv_np);
+            if (sr.pool == rsv_np) rsv_np = -1; // (used)
             ph = p.use_dirichlet ? PH_NEED_ROOT : PH_RUN;
         }
     }
@@ -538,6 +660,7 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         if (nc == 0 || (tot <= 0 && p.arena_agent != AZ_ARENA_NET)) fault |= AZ_FAULT_NO_VISITS;
         if (sr.rs.ply >= p.max_plies || sr.gid >= p.max_games || sr.gid < 0) fault |= AZ_FAULT_PLY_OVERFLOW;
         if (fault) {
+            release_rsv();
             if (lane == 0) {
                 p.phase[g] = PH_IDLE;
                 atomicOr(p.faults, fault);
@@ -636,10 +759,14 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         int term = az_apply<GAME>(sr.rs, geom, action, &ret0); // game_utils.py:197
         sr.sims = 0;
         if (term) {
-            if (!finish_game_take_next(p, g, lane, sr, ret0, st_moves)) return;
+            if (!finish_game_take_next(p, g, lane, sr, ret0, st_moves)) {
+                release_rsv();
+                return;
+            }
             reroot(p, g, sr, t, -1, true, start_rule(p), lane, fault, st_compact);
         } else {
-            reroot(p, g, sr, t, sel, !p.keep_tree, p.keep_tree ? p.select_rule : AZ_SELECT_PUCT, lane, fault, st_compact);
+            reroot(p, g, sr, t, sel, !p.keep_tree, p.keep_tree ? p.select_rule : AZ_SELECT_PUCT, lane, fault, st_compact, rsv_k, rsv_np);
+            if (sr.pool == rsv_np) rsv_np = -1; // (used)
         }
         ph = opponent_to_move(p, sr.gid, sr.rs) ? PH_OPPONENT : (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN);
     }
@@ -666,6 +793,7 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
     }
     fault = wave_or(fault);
     if (lane == 0) {
+        if (rsv_np >= 0) atomicExch(&p.spare[rsv_k], rsv_np); // reserved, not needed after all (game over, fresh tree, leaf root)
         slot_store(p, g, sr, fault ? PH_IDLE : ph);
         unsigned long long *st = p.stats + (size_t)g * ST_N;
         st[ST_MOVES] += st_moves;
@@ -1146,6 +1274,7 @@ __global__ void az_reset_kernel(Params p) {
     p.which[g] = g | (!p.keep_tree || p.manual_moves ? AZ_SELECT_PUCT
                       : (p.start.ply >= (p.arena_agent == AZ_ARENA_SELF_PLAY ? 1 : 2) ? p.select_rule : AZ_SELECT_PUCT)) << 30; // pool g, start_rule
     for (int k = g; k < p.n_spare; k += p.G) p.spare[k] = p.G + k; // the spare pools follow the slots' own
+    if (g == 0) p.cjob_count[0] = p.cjob_count[1] = 0;
     p.root[g] = 0;
     p.alloc[g] = 1;
     p.depth[g] = 0;
@@ -1313,8 +1442,7 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     p.uct_cap = c.arena_opponent == AZ_OPPONENT_UCT ? (uint32_t)(1 + (size_t)c.opponent_sims * p.maxc) : 0;
     p.need_per_move = (uint32_t)((c.n_playouts + 1) * p.maxc);
     // default pool: room for 48 searches, or for the whole game if it is shorter (connect_four: 42 plies -> a slot never
-    // compacts; every compaction is a ~100-400 us single-wave Cheney copy that holds the whole launch), capped so that the
-    // pools take at most half of the free HBM.  Measured, connect_four S=400, 4096 slots: 6 searches 10k compactions per
+    // compacts), capped so that the pools take at most a quarter of the free HBM.  Measured, connect_four S=400, 4096 slots: 6 searches 10k compactions per
     // 4096 games, 24 searches 820, whole game none: +1.7 % games/s over 24, 31 GB instead of 18 GB.
     // Spare pools (round 3): a slot owns ONE pool; the target of a compaction comes from a shared set of spare pools (default
     // n_slots / 16, at least 16, at most n_slots) instead of a private second half per slot - the same capacity per slot in
@@ -1326,7 +1454,9 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
     if (c.nodes_per_slot <= 0) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            int64_t fit = (int64_t)(free_b / 2 / ((size_t)(c.n_slots + p.n_spare) * sizeof(AzNode)));
+            // (a QUARTER of the free HBM - it was half until compaction left the critical path: breakthrough 6x6, S = 800, 4096
+            //  slots: 155 GB and no compaction -> 78 GB, a few hundred cheap ones per 8192 games, -1..3 % games/s)
+            int64_t fit = (int64_t)(free_b / 4 / ((size_t)(c.n_slots + p.n_spare) * sizeof(AzNode)));
             int64_t floor_cap = (int64_t)3 * p.need_per_move + 64;
             if (cap > fit) cap = fit > floor_cap ? fit : floor_cap;
         }
@@ -1337,6 +1467,9 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
         return AZ_E_INVALID;
     }
     p.cap = (uint32_t)cap;
+    p.defer_compact = 0;
+    // (with tree reuse a pool grows by at most need_per_move nodes per move: one that holds max_plies searches never compacts)
+    e->may_compact = c.keep_search_tree && !c.manual_moves && cap < (int64_t)p.max_plies * p.need_per_move + 64;
     p.c_puct = c.c_puct;
     p.one_minus_ratio = 1.0 - c.dirichlet_ratio;
     p.alpha = c.dirichlet_alpha > 0 ? c.dirichlet_alpha : 0.3;
@@ -1365,6 +1498,7 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
 #define DA(ptr, n) if (rc == AZ_OK) rc = dalloc(e, &(ptr), (n))
     DA(p.nodes, nodes);
     DA(p.spare, (size_t)p.n_spare);
+    DA(p.cjob_list, G); DA(p.cjob_count, 2); DA(p.cj_from, G); DA(p.cj_entry, G); DA(p.cj_root, G);
     DA(p.row_slot, G); DA(p.req_row, G); DA(p.n_rows_live, 1);
     DA(p.phase, G); DA(p.gid, G); DA(p.ply, G); DA(p.sims, G); DA(p.which, G); DA(p.depth, G); DA(p.leaf_ply, G);
     DA(p.root, G); DA(p.alloc, G); DA(p.leaf_node, G); DA(p.path, G * p.pstride);
@@ -1499,16 +1633,23 @@ extern "C" int az_engine_set_start_prefix(az_engine *e, const int32_t *actions, 
     return AZ_OK;
 }
 
+// `defer`: compactions of this launch are queued for az_compact_kernel, enqueued right behind the tick kernel on the same stream
+// (whole-engine launches only: the job queue is one per engine, and slot groups ticking on their own streams would share it).
 template <bool MAPPED>
-static int advance_range(az_engine *e, int g_first, int g_end, const float *priors, const float *values, float *obs_out, void *stream) {
+static int advance_range(az_engine *e, int g_first, int g_end, const float *priors, const float *values, float *obs_out, void *stream,
+                         bool defer) {
     HIPCHK(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((g_end - g_first + 3) / 4), block(256);
+    defer = defer && e->may_compact;
+    e->p.defer_compact = defer ? 1 : 0;
     if (e->cfg.game == AZ_GAME_CONNECT_FOUR) {
         hipLaunchKernelGGL((az_advance_kernel<AZG_CONNECT_FOUR, 1, MAPPED>), grid, block, 0, st, e->p, g_first, g_end, priors, values, obs_out);
     } else {
         hipLaunchKernelGGL((az_advance_kernel<AZG_BREAKTHROUGH, 3, MAPPED>), grid, block, 0, st, e->p, g_first, g_end, priors, values, obs_out);
     }
+    if (defer) hipLaunchKernelGGL(az_compact_kernel, dim3(AZ_COMPACT_WGS), dim3(CJ_THREADS), 0, st, e->p);
+    e->p.defer_compact = 0;
     HIPCHK(e, hipGetLastError());
     return AZ_OK;
 }
@@ -1567,7 +1708,7 @@ extern "C" int az_engine_advance(az_engine *e, const float *priors, const float 
         e->err = "az_engine_advance after az_engine_compact_rows: the requests now live in dense rows, use az_engine_advance_rows";
         return AZ_E_STATE;
     }
-    rc = advance_range<false>(e, 0, e->p.G, priors, values, obs_out, stream);
+    rc = advance_range<false>(e, 0, e->p.G, priors, values, obs_out, stream, true);
     if (rc == AZ_OK) e->ticks++;
     return rc;
 }
@@ -1614,7 +1755,7 @@ extern "C" int az_engine_advance_rows(az_engine *e, int32_t n_rows, const float 
         return AZ_E_INVALID;
     }
     if (e->rows_live == 0) return AZ_OK;
-    rc = advance_range<true>(e, 0, e->rows_live, priors, values, obs_out, stream);
+    rc = advance_range<true>(e, 0, e->rows_live, priors, values, obs_out, stream, true);
     if (rc == AZ_OK) e->ticks++;
     return rc;
 }
@@ -1631,7 +1772,7 @@ extern "C" int az_engine_advance_slots(az_engine *e, int32_t first_slot, int32_t
         e->err = "az_engine_advance_slots after az_engine_compact_rows: use az_engine_advance_rows";
         return AZ_E_STATE;
     }
-    rc = advance_range<false>(e, first_slot, first_slot + n_slots, priors, values, obs_out, stream);
+    rc = advance_range<false>(e, first_slot, first_slot + n_slots, priors, values, obs_out, stream, false);
     if (rc == AZ_OK) e->ticks++;
     return rc;
 }

@@ -49,6 +49,12 @@ struct Params {
     AzNode *nodes;
     int n_spare;
     int *spare;
+    // deferred compaction (az_compact_kernel): a slot that must compact while re-rooting takes a spare pool, becomes its owner
+    // (root 0) and queues a job; the copy runs in a kernel of its own right after the tick kernel, a workgroup per job.
+    int defer_compact;              // this launch may queue jobs (set per launch by the host)
+    int *cjob_list, *cjob_count;    // [G] queued slots, their number; cjob_count[1] = workgroups of az_compact_kernel done
+    int *cj_from, *cj_entry;        // [G] the pool the subtree is copied out of; the spare[] entry that takes it back
+    uint32_t *cj_root;              // [G] index of the new root in that pool
     // per slot
     int *phase, *gid, *ply, *sims, *which, *depth, *leaf_ply;
     uint32_t *root, *alloc, *leaf_node, *path;
@@ -99,6 +105,7 @@ struct az_engine {
     int64_t inj_games = 0;
     bool rows_mapped = false; // az_engine_compact_rows has been called since the last reset
     int rows_live = 0;
+    bool may_compact = false; // a pool cannot hold a whole game: re-rooting may have to compact (az_compact_kernel is enqueued per tick)
     // host mirrors for export
     std::vector<int32_t> h_len;
     std::vector<float> h_ret0;
