@@ -446,6 +446,36 @@ def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_tick
     (a board's evaluation does not depend on its row)."""
     if overlap > 1:
         return _run_selfplay_overlapped(engine, evaluator, n_games, seed, check_every, max_ticks, use_graph, overlap)
+    steps = selfplay_steps(engine, evaluator, n_games, seed, check_every, max_ticks, use_graph, on_tick, ticks_per_graph, compact_tail)
+    while True:
+        try:
+            next(steps)
+        except StopIteration as stop:
+            return stop.value
+
+
+def run_selfplay_pools(engines, evaluators, n_games_each, **kw):
+    """k engines - one per "pool" of the reference (examplegenerator.py:140-162: n_pools = the amount of GPUs to utilize), each on
+    its own device - driven from ONE host thread: every pass enqueues a batch of ticks on each device and only then waits for
+    the batch before, so the devices run side by side.  -> list of the final progress dicts."""
+    gens = [selfplay_steps(e, ev, n_games_each, **kw) for e, ev in zip(engines, evaluators)]
+    out = [None] * len(gens)
+    live = list(range(len(gens)))
+    while live:
+        for i in list(live):
+            try:
+                with torch.cuda.device(engines[i].device):
+                    next(gens[i])
+            except StopIteration as stop:
+                out[i] = stop.value
+                live.remove(i)
+    return out
+
+
+def selfplay_steps(engine, evaluator, n_games, seed=None, check_every=32, max_ticks=None, use_graph=False, on_tick=None,
+                   ticks_per_graph=16, compact_tail=True):
+    """Generator form of run_selfplay (one stream): yields after every batch of enqueued ticks, BEFORE it waits for them;
+    the final progress dict is the generator's return value."""
     engine.reset(n_games, seed)
     obs, pri, val = engine.alloc_io()
     ticks = 0
@@ -490,6 +520,7 @@ def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_tick
                 ticks += 1
             if on_tick is not None:
                 on_tick(engine, ticks)
+        yield ticks  # (a driver of several engines enqueues the others' batches here)
         done = engine.games_done()
         if done >= n_games:
             break

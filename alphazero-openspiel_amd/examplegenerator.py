@@ -33,8 +33,12 @@ class ExampleGenerator:
         self.net = copy.deepcopy(net)  # examplegenerator.py:86: a frozen copy of the current net
         self.game_name = game_name
         self.game = Game(game_name)
-        self.n_pools, self.n_processes = int(n_pools), n_processes  # no pools / worker processes here (module doc); n_pools only
-                                                                    # reproduces the reference's game COUNT
+        # n_pools = "amount of GPUs to utilize" (train.py:32): with several HIP devices visible to ONE process (no torch.distributed)
+        # pool i is an engine of its own on the device the reference would pick (examplegenerator.py:144-150) and plays
+        # int(n_games / n_pools) games; on one device the pools collapse into one engine that plays the same COUNT.
+        # pool_devices=[...] names the devices explicitly (also: several pools on one device, which is how the path is tested).
+        self.n_pools, self.n_processes = int(n_pools), n_processes  # (no worker processes here: module doc)
+        self.pool_devices = kwargs.get("pool_devices")
         self.kwargs = kwargs
         # engine extensions (not reference keywords)
         self.n_slots = kwargs.get("n_slots")           # concurrent games per GPU; default min(n_games, 4096)
@@ -52,9 +56,64 @@ class ExampleGenerator:
     def _engine_kwargs(self):
         return {k: self.kwargs[k] for k in _ENGINE_KW if k in self.kwargs}
 
+    def _pool_device_list(self):
+        """Devices of the reference's pools when this one process drives several GPUs, else None (one engine)."""
+        if self.pool_devices is not None:
+            return [torch.device(d) for d in self.pool_devices]
+        n_dev = torch.cuda.device_count()
+        if self.n_pools < 2 or n_dev < 2 or azdist.world_size() > 1:
+            return None
+        devs, device_no = [], 1  # examplegenerator.py:144-150: the first pool goes to cuda:1, the count wraps to cuda:0
+        for _ in range(self.n_pools):
+            if device_no >= n_dev:
+                device_no = 0
+            devs.append(torch.device("cuda", device_no))
+            device_no += 1
+        return devs
+
+    def _play_pools(self, n_games, devices):
+        """One engine + evaluator per pool, each on its device, driven from this thread (engine.run_selfplay_pools); the pools'
+        packed records are brought to self.device and laid out like the ranks of an all-gather."""
+        from .engine import run_selfplay_pools
+        n_each = int(n_games / len(devices))
+        if n_each < 1:
+            raise ValueError("n_games=%d is fewer than the %d pools" % (n_games, len(devices)))
+        n_slots = int(self.n_slots or min(n_each, 4096))
+        engines, evaluators = [], []
+        try:
+            for i, dev in enumerate(devices):
+                with torch.cuda.device(dev):
+                    engines.append(SelfPlayEngine(self.game, n_slots, max_games=n_each, device=dev,
+                                                  seed=self.seed + 1000003 * self._generation + 7919 * i, **self._engine_kwargs()))
+                    if self.eval_backend == "fused":
+                        from .fusednet import FusedNet
+                        evaluators.append(FusedNet(self.net, dev, max_boards=n_slots, precision=self.eval_precision))
+                    else:
+                        evaluators.append(DeviceEvaluator(copy.deepcopy(self.net), dev, dtype=self.eval_dtype))
+            progs = run_selfplay_pools(engines, evaluators, n_each, use_graph=self.use_graph)
+            self.last_progress = progs[0]
+            bufs = []
+            for e in engines:
+                with torch.cuda.device(e.device):
+                    b = e.export_device()
+                    torch.cuda.current_stream(e.device).synchronize()
+                bufs.append(b.to(self.device))
+            dims = (engines[0].max_plies, engines[0].max_children)
+        finally:
+            for e in engines:
+                e.close()
+            for ev in evaluators:
+                if hasattr(ev, "close"):
+                    ev.close()
+        self._generation += 1
+        return torch.cat(bufs), bufs[0].numel(), n_each, len(devices), dims
+
     def _play_and_gather(self, n_games):
         """This rank's shard of the generation on the HIP engine, then the generation-end exchange on DEVICE buffers.
         -> (gathered uint8 device tensor [world * nbytes], nbytes per rank, games per rank, world, (max_plies, max_children))"""
+        pool_devs = self._pool_device_list()
+        if pool_devs is not None:
+            return self._play_pools(n_games, pool_devs)
         world, rank = azdist.world_size(), azdist.rank()
         if world == 1:  # the reference plays int(n_games / n_pools) games in each of its n_pools pools (examplegenerator.py:149):
             n_local = int(n_games / self.n_pools) * self.n_pools if self.n_pools > 1 else int(n_games)  # same count here
