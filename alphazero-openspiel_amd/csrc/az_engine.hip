@@ -427,18 +427,19 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, b
         }
         st_compact++;
         if (rsv_np >= 0) {
-            // queue the copy for az_compact_kernel (it runs right after this kernel, a workgroup per job, and writes alloc[g]);
-            // nothing in the rest of this tick touches the tree, and the next tick finds it at node 0 of the new pool
+            // queue the copy for the extra workgroups of the NEXT tick's launch (compact_jobs: a workgroup per job; it writes
+            // alloc[g]); nothing in the rest of this tick touches the tree, the slot sits the next tick out (PH_COMPACTING, set
+            // by the caller) and then finds its tree at node 0 of the new pool
             if (lane == 0) {
-                const int j = atomicAdd(p.cjob_count, 1);
-                p.cjob_list[j] = g;
+                const int j = atomicAdd(p.cjob_count + p.cj_parity, 1);
+                p.cjob_list[(size_t)p.cj_parity * p.G + j] = g;
                 p.cj_from[g] = sr.pool;
                 p.cj_entry[g] = k;
                 p.cj_root[g] = sr.root;
             }
             sr.root = 0;
             sr.pool = np;
-            sr.alloc = p.cap; // (placeholder: az_compact_kernel stores the live count)
+            sr.alloc = p.cap; // (placeholder: compact_jobs stores the live count)
             t = pool_at(p, np);
             return;
         }
@@ -453,19 +454,22 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, b
     }
 }
 
-// Deferred compaction: one 256-thread workgroup per queued slot copies the subtree under cj_root[g] of pool cj_from[g] into the
-// slot's new pool, breadth first, 256 parents per round: the children of a round are numbered by a block-wide prefix sum (the
-// SAME order - hence the same node indices - as compact_subtree's wave-wide one) and copied one node per thread and step,
-// so a round is two or three memory round trips whatever the fan-out.  The last workgroup to finish clears the queue.
+// Deferred compaction: the last AZ_COMPACT_WGS workgroups of a tick kernel launch work off the jobs the launch BEFORE queued
+// (list 1 - cj_parity), beside the slots' own waves - the queued slots sit this tick out.  One 256-thread workgroup per job copies
+// the subtree under cj_root[g] of pool cj_from[g] into the slot's new pool, breadth first, 256 parents per round: the children of a
+// round are numbered by a block-wide prefix sum (the SAME order - hence the same node indices - as compact_subtree's wave-wide
+// one) and copied one node per thread and step, so a round is two or three memory round trips whatever the fan-out.  The last
+// workgroup to finish clears the list.  (It was a kernel of its own for a day: 4.9 us per tick, empty or not.)
 #define CJ_THREADS 256
-#define AZ_COMPACT_WGS 64 // workgroups of az_compact_kernel (jobs are rare; a burst is worked off 64 at a time)
-__global__ __launch_bounds__(CJ_THREADS) void az_compact_kernel(Params p) {
+#define AZ_COMPACT_WGS 64 // extra workgroups per launch (jobs are rare; a burst is worked off 64 at a time)
+__device__ void compact_jobs(const Params &p, const int wg, const int n_wg) {
     __shared__ uint32_t sh_off[CJ_THREADS + 1], sh_c0[CJ_THREADS];
     __shared__ int sh_wave[CJ_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n_jobs = p.cjob_count[0];
-    for (int job = blockIdx.x; job < n_jobs; job += gridDim.x) {
-        const int g = p.cjob_list[job];
+    const int par = 1 - p.cj_parity;
+    const int n_jobs = p.cjob_count[par];
+    for (int job = wg; job < n_jobs; job += n_wg) {
+        const int g = p.cjob_list[(size_t)par * p.G + job];
         const Pool a = pool_at(p, p.cj_from[g]), b = pool_at(p, p.which[g] & POOL_MASK);
         if (tid == 0) b.nd[0] = a.nd[p.cj_root[g]]; // C0 is still an OLD index until scanned
         __threadfence_block();
@@ -522,9 +526,9 @@ __global__ __launch_bounds__(CJ_THREADS) void az_compact_kernel(Params p) {
     }
     if (tid == 0) {
         __threadfence();
-        if (atomicAdd(p.cjob_count + 1, 1) == (int)gridDim.x - 1) { // every workgroup has read n_jobs and finished its jobs
-            p.cjob_count[0] = 0;
-            p.cjob_count[1] = 0;
+        if (atomicAdd(p.cjob_count + 2, 1) == n_wg - 1) { // every extra workgroup has read n_jobs and finished its jobs
+            p.cjob_count[par] = 0;
+            p.cjob_count[2] = 0;
         }
     }
 }
@@ -580,7 +584,7 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
     Pool t = pool_at(p, sr.pool);
     unsigned long long st_moves = 0, st_evals = 0, st_compact = 0;
     unsigned int fault = 0;
-    // Deferred compaction (az_compact_kernel): if this move may have to compact, RESERVE the spare pool before anything is
+    // Deferred compaction (compact_jobs): if this move may have to compact, RESERVE the spare pool before anything is
     // changed; a slot that finds none free (they are all with jobs queued in this launch) simply returns - its phase and state
     // are untouched, it repeats the move step next tick, after the queued copies have handed their pools back.
     int rsv_k = -1, rsv_np = -1;
@@ -601,6 +605,7 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         rsv_np = __shfl(rsv_np, 0);
         if (rsv_np < 0) return;
     }
+    bool queued = false; // the re-rooting of this move queued a compaction: the slot resumes after the next tick
     auto release_rsv = [&]() { // (paths that leave the move step early hand an unused reservation back)
         if (rsv_np >= 0 && lane == 0) atomicExch(&p.spare[rsv_k], rsv_np);
         rsv_np = -1;
@@ -637,7 +642,10 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         } else { // a leaf root here = the agent's first step of the game: update_root runs only with >= 2 moves played
             reroot(p, g, sr, t, sel, !p.keep_tree, (p.keep_tree && sr.rs.ply >= 2) ? p.select_rule : AZ_SELECT_PUCT, lane, fault,
                    st_compact, rsv_k, rsv_np);
-            if (sr.pool == rsv_np) rsv_np = -1; // (used)
+            if (sr.pool == rsv_np) {
+                rsv_np = -1; // (used)
+                queued = true;
+            }
             ph = p.use_dirichlet ? PH_NEED_ROOT : PH_RUN;
         }
     }
@@ -766,7 +774,10 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
             reroot(p, g, sr, t, -1, true, start_rule(p), lane, fault, st_compact);
         } else {
             reroot(p, g, sr, t, sel, !p.keep_tree, p.keep_tree ? p.select_rule : AZ_SELECT_PUCT, lane, fault, st_compact, rsv_k, rsv_np);
-            if (sr.pool == rsv_np) rsv_np = -1; // (used)
+            if (sr.pool == rsv_np) {
+                rsv_np = -1; // (used)
+                queued = true;
+            }
         }
         ph = opponent_to_move(p, sr.gid, sr.rs) ? PH_OPPONENT : (p.use_dirichlet ? PH_NEED_ROOT : PH_RUN);
     }
@@ -794,7 +805,8 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
     fault = wave_or(fault);
     if (lane == 0) {
         if (rsv_np >= 0) atomicExch(&p.spare[rsv_k], rsv_np); // reserved, not needed after all (game over, fresh tree, leaf root)
-        slot_store(p, g, sr, fault ? PH_IDLE : ph);
+        if (queued && !fault) p.cj_phase[g] = ph;
+        slot_store(p, g, sr, fault ? PH_IDLE : (queued ? PH_COMPACTING : ph));
         unsigned long long *st = p.stats + (size_t)g * ST_N;
         st[ST_MOVES] += st_moves;
         st[ST_EVALS] += st_evals;
@@ -812,6 +824,11 @@ template <int GAME, int NP, bool MAPPED>
 __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_first, const int g_end, const float *__restrict__ priors,
                                                          const float *__restrict__ values, float *__restrict__ obs_out) {
     const int lane = threadIdx.x & 63;
+    const int n_slot_wgs = (g_end - g_first + 3) >> 2;
+    if ((int)blockIdx.x >= n_slot_wgs) { // (only launched when p.defer_compact) the jobs the launch before queued
+        compact_jobs(p, (int)blockIdx.x - n_slot_wgs, (int)gridDim.x - n_slot_wgs);
+        return;
+    }
     const int row = g_first + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= g_end) return;
     const int g = MAPPED ? rfl(p.row_slot[row]) : row;
@@ -835,6 +852,10 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
                                                                     // root request: ends this slot's tick
         if (MAPPED && lane == 0) p.req_row[g] = row;
         move_step<GAME>(p, g, lane, ph, sr, obs_row);
+        return;
+    }
+    if (ph == PH_COMPACTING) { // this launch's extra workgroups are copying the slot's tree: resume next tick (alloc[g] is theirs)
+        if (lane == 0) p.phase[g] = p.cj_phase[g];
         return;
     }
     if (ph != PH_RUN && ph != PH_WAIT_LEAF && ph != PH_WAIT_ROOT) return;
@@ -1274,7 +1295,7 @@ __global__ void az_reset_kernel(Params p) {
     p.which[g] = g | (!p.keep_tree || p.manual_moves ? AZ_SELECT_PUCT
                       : (p.start.ply >= (p.arena_agent == AZ_ARENA_SELF_PLAY ? 1 : 2) ? p.select_rule : AZ_SELECT_PUCT)) << 30; // pool g, start_rule
     for (int k = g; k < p.n_spare; k += p.G) p.spare[k] = p.G + k; // the spare pools follow the slots' own
-    if (g == 0) p.cjob_count[0] = p.cjob_count[1] = 0;
+    if (g == 0) p.cjob_count[0] = p.cjob_count[1] = p.cjob_count[2] = 0;
     p.root[g] = 0;
     p.alloc[g] = 1;
     p.depth[g] = 0;
@@ -1498,7 +1519,7 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
 #define DA(ptr, n) if (rc == AZ_OK) rc = dalloc(e, &(ptr), (n))
     DA(p.nodes, nodes);
     DA(p.spare, (size_t)p.n_spare);
-    DA(p.cjob_list, G); DA(p.cjob_count, 2); DA(p.cj_from, G); DA(p.cj_entry, G); DA(p.cj_root, G);
+    DA(p.cjob_list, 2 * G); DA(p.cjob_count, 3); DA(p.cj_from, G); DA(p.cj_entry, G); DA(p.cj_phase, G); DA(p.cj_root, G);
     DA(p.row_slot, G); DA(p.req_row, G); DA(p.n_rows_live, 1);
     DA(p.phase, G); DA(p.gid, G); DA(p.ply, G); DA(p.sims, G); DA(p.which, G); DA(p.depth, G); DA(p.leaf_ply, G);
     DA(p.root, G); DA(p.alloc, G); DA(p.leaf_node, G); DA(p.path, G * p.pstride);
@@ -1566,6 +1587,7 @@ extern "C" int az_engine_reset(az_engine *e, uint64_t seed, int64_t n_games, voi
     HIPCHK(e, hipGetLastError());
     e->reset_done = true;
     e->ticks = 0;
+    e->cj_parity = 0;
     e->rows_mapped = false;
     e->rows_live = 0;
     return AZ_OK;
@@ -1633,22 +1655,23 @@ extern "C" int az_engine_set_start_prefix(az_engine *e, const int32_t *actions, 
     return AZ_OK;
 }
 
-// `defer`: compactions of this launch are queued for az_compact_kernel, enqueued right behind the tick kernel on the same stream
-// (whole-engine launches only: the job queue is one per engine, and slot groups ticking on their own streams would share it).
+// `defer`: compactions of this launch are queued for the extra workgroups of the NEXT such launch (compact_jobs; whole-engine
+// launches only: the job lists are one pair per engine, and slot groups ticking on their own streams would share them).
 template <bool MAPPED>
 static int advance_range(az_engine *e, int g_first, int g_end, const float *priors, const float *values, float *obs_out, void *stream,
                          bool defer) {
     HIPCHK(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((g_end - g_first + 3) / 4), block(256);
     defer = defer && e->may_compact;
+    dim3 grid((g_end - g_first + 3) / 4 + (defer ? AZ_COMPACT_WGS : 0)), block(256);
     e->p.defer_compact = defer ? 1 : 0;
+    e->p.cj_parity = e->cj_parity;
+    if (defer) e->cj_parity ^= 1;
     if (e->cfg.game == AZ_GAME_CONNECT_FOUR) {
         hipLaunchKernelGGL((az_advance_kernel<AZG_CONNECT_FOUR, 1, MAPPED>), grid, block, 0, st, e->p, g_first, g_end, priors, values, obs_out);
     } else {
         hipLaunchKernelGGL((az_advance_kernel<AZG_BREAKTHROUGH, 3, MAPPED>), grid, block, 0, st, e->p, g_first, g_end, priors, values, obs_out);
     }
-    if (defer) hipLaunchKernelGGL(az_compact_kernel, dim3(AZ_COMPACT_WGS), dim3(CJ_THREADS), 0, st, e->p);
     e->p.defer_compact = 0;
     HIPCHK(e, hipGetLastError());
     return AZ_OK;

@@ -12,7 +12,8 @@
 #define NONE32 0xFFFFFFFFu
 
 enum { PH_IDLE = 0, PH_RUN = 1, PH_MOVE = 2, PH_WAIT_ROOT = 3, PH_WAIT_LEAF = 4, PH_SEARCH_DONE = 5, PH_NEED_ROOT = 6,
-       PH_OPPONENT = 7 /* arena: the opponent bot is to move */, PH_OPP_DONE = 8 /* ... and has chosen (opp_action) */ };
+       PH_OPPONENT = 7 /* arena: the opponent bot is to move */, PH_OPP_DONE = 8 /* ... and has chosen (opp_action) */,
+       PH_COMPACTING = 9 /* its subtree is being copied into a new pool by this launch's extra workgroups: sits the tick out */ };
 enum { ST_MOVES = 0, ST_SIMS, ST_EVALS, ST_TERM, ST_DEPTH, ST_CHILDREN, ST_NODES, ST_COMPACT, ST_N };
 
 // One search-tree node (mcts.py:10-20 Node: N, Q, P, children).  32 bytes, so a block of sibling nodes is one
@@ -49,11 +50,12 @@ struct Params {
     AzNode *nodes;
     int n_spare;
     int *spare;
-    // deferred compaction (az_compact_kernel): a slot that must compact while re-rooting takes a spare pool, becomes its owner
-    // (root 0) and queues a job; the copy runs in a kernel of its own right after the tick kernel, a workgroup per job.
-    int defer_compact;              // this launch may queue jobs (set per launch by the host)
-    int *cjob_list, *cjob_count;    // [G] queued slots, their number; cjob_count[1] = workgroups of az_compact_kernel done
-    int *cj_from, *cj_entry;        // [G] the pool the subtree is copied out of; the spare[] entry that takes it back
+    // deferred compaction: a slot that must compact while re-rooting takes a spare pool, becomes its owner (root 0), queues a
+    // job and sits the NEXT tick out (PH_COMPACTING) while that tick's extra workgroups copy the subtree, a workgroup per job.
+    int defer_compact;              // this launch may queue jobs and carries the extra workgroups (set per launch by the host)
+    int cj_parity;                  // jobs queued by this launch go to list cj_parity; its extra workgroups work off list 1 - cj_parity
+    int *cjob_list, *cjob_count;    // [2][G] queued slots; cjob_count[0..1] = their numbers, [2] = extra workgroups done
+    int *cj_from, *cj_entry, *cj_phase; // [G] the pool the subtree is copied out of; the spare[] entry that takes it back; the phase to resume in
     uint32_t *cj_root;              // [G] index of the new root in that pool
     // per slot
     int *phase, *gid, *ply, *sims, *which, *depth, *leaf_ply;
@@ -105,7 +107,8 @@ struct az_engine {
     int64_t inj_games = 0;
     bool rows_mapped = false; // az_engine_compact_rows has been called since the last reset
     int rows_live = 0;
-    bool may_compact = false; // a pool cannot hold a whole game: re-rooting may have to compact (az_compact_kernel is enqueued per tick)
+    bool may_compact = false; // a pool cannot hold a whole game: re-rooting may have to compact (launches carry extra workgroups)
+    int cj_parity = 0;        // job list the next deferred launch queues into
     // host mirrors for export
     std::vector<int32_t> h_len;
     std::vector<float> h_ret0;
