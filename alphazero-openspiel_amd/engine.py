@@ -424,9 +424,10 @@ def slot_groups(n_slots, k):
 
 
 def _tail_levels(n_slots):
-    """Row counts worth switching to as a generation thins out: the fused tower runs 256 workgroups of 8 (4) boards per round,
-    so its time steps down at n_slots/2 and n_slots/4 (4096 boards 202 us, 2048: 109 us, 1024: 72 us, 512: 66 us)."""
-    return [n for n in (n_slots // 2, n_slots // 4) if n >= 512]
+    """Row counts worth switching to as a generation thins out.  The fused towers run 256 workgroups per round: the fp32-grade
+    one (the default) takes 511 / 276 / 150 us at 4096 / 2048 / 1024 boards with a board per wave, and 120 / 67 us at 512 / 256
+    with a board per workgroup (az_tower_x3c_kernel; profiles/r3_tower_vs_boards.txt) - so halve down to 256 rows."""
+    return [n for n in (n_slots // 2, n_slots // 4, n_slots // 8, n_slots // 16) if n >= 256]
 
 
 def run_selfplay(engine, evaluator, n_games, seed=None, check_every=32, max_ticks=None, use_graph=False,

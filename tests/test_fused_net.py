@@ -163,16 +163,24 @@ def test_fused_f32x_forward_is_fp32_grade(tag, n):
 
 
 @pytest.mark.gpu
-def test_fused_f32x_outputs_do_not_depend_on_the_batch_size():
-    game, net = _nets()["c4_10block"]
+@pytest.mark.parametrize("tag", ["c4_10block", "bt6_10block", "bt5x4_3block"])
+def test_fused_f32x_outputs_do_not_depend_on_the_batch_size(tag):
+    """The fp32-grade tower has a board-per-wave kernel (az_tower_x3b_kernel, > 512 boards) and a board-per-workgroup kernel for
+    small batches (az_tower_x3c_kernel: the four waves split a board by output-channel tile): priors, value and tower output of
+    a board must be the same BITS in both - a generation's records may not depend on when its tail switches kernels."""
+    game, net = _nets()[tag]
     fn = fusednet.FusedNet(net, "cuda:0", max_boards=1024, precision="f32x")
     torch.manual_seed(5)
-    obs = (torch.rand(1024, 4, 6, 7, device="cuda") > 0.5).float()
+    obs = (torch.rand(1024, 4, game.rows, game.cols, device="cuda") > 0.5).float()
     ref_p, ref_v = [t.clone() for t in fn.forward(obs)]
-    for n in (512, 300, 64, 5):
+    torch.cuda.synchronize()
+    ref_t = fn.read_tower(1024)
+    assert "x3b" in fn.kernel_label()
+    for n in (700, 512, 300, 256, 64, 5, 1):
         p, v = fn.forward(obs[:n].contiguous())
         torch.cuda.synchronize()
         assert torch.equal(p, ref_p[:n]) and torch.equal(v, ref_v[:n]), n
+        assert (fn.read_tower(n) == ref_t[:n]).all(), n
     fn.close()
 
 
