@@ -1119,15 +1119,22 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
 // Arena opponents (evaluation games, game_utils.py:16-145): ONE THREAD per slot whose opponent is to move.
 //  * AZ_OPPONENT_RANDOM - pyspiel.make_uniform_random_bot: a uniformly random legal action.
 //  * AZ_OPPONENT_UCT    - open_spiel.python.algorithms.mcts.MCTSBot(game, player, uct_c, max_search_nodes,
-//    RandomRolloutEvaluator(1)).  OpenSpiel is a third-party dependency absent from the reference tree and unpinned
-//    (SURVEY.md 8(c)); this restates the published algorithm: per simulation descend from the root while the node has
-//    been visited (children are created the first time a visited node is descended through), choosing the child that
-//    maximises  total_reward / explore_count + uct_c * sqrt(log(parent explore_count) / explore_count)  (an unvisited
-//    child counts as +infinity; ties -> first in legal-action order), evaluate the reached node by ONE uniformly random
-//    rollout to the end of the game (terminal nodes by their return), add the result to every node of the path as seen
-//    by the player who moved into it; finally play the most visited root child (ties -> first).
+//    RandomRolloutEvaluator(1)) with its defaults solve=True, child_selection_fn=uct_value.  OpenSpiel is a third-party
+//    dependency absent from the reference tree and unpinned; this restates the published algorithm: per
+//    simulation descend from the root while the node has been visited (a visited node gets its children the first time it is
+//    descended through, in an order SHUFFLED by the bot's random state - here Fisher-Yates on the Philox stream), choosing
+//    the child that maximises its proven outcome for the mover if it has one, else  total_reward / explore_count + uct_c *
+//    sqrt(log(parent explore_count) / explore_count)  (an unvisited child counts as +infinity; first maximum in child
+//    order); a terminal node takes its returns as outcome, any other leaf ONE uniformly random rollout to the end of the
+//    game; the result is added to every node of the path as seen by the player who moved into it; MCTS-Solver: while the
+//    backup is "solved", a node all of whose children are solved, or one of whose children is a proven win for the player
+//    to move, takes the outcome of its best child; the search stops when the root is solved; finally the child with the
+//    largest (proven outcome for the mover or 0, explore_count, total_reward) is played (first maximum).
 // Random numbers: Philox stream (seed, game id, ply, purpose 2), consumed in simulation order, so that the C restatement
-// in oracle/az_oracle.c reproduces every move bit for bit.
+// in oracle/az_oracle.c reproduces every move bit for bit.  META: action | n_children << 16 | outcome code << 24
+// (0 = open, 1 / 2 / 3 = player 0's return is -1 / 0 / +1).
+#define UCT_NCH(m) (int)(((m) >> 16) & 0xFFu)
+#define UCT_OUT(m) (int)(((m) >> 24) & 0x7u)
 template <int GAME> __device__ int uct_search(const Params &p, int g, const AzState &root_s, Philox &r) {
     const AzGeom &geom = p.geom;
     uint32_t *N = p.uct_N + (size_t)g * p.uct_cap, *C0 = p.uct_C0 + (size_t)g * p.uct_cap, *META = p.uct_META + (size_t)g * p.uct_cap;
@@ -1146,27 +1153,37 @@ template <int GAME> __device__ int uct_search(const Params &p, int g, const AzSt
         float ret0 = 0.f;
         path[0] = 0;
         while (!term && N[node] > 0) {
-            if (C0[node] == NONE32) { // first descent through a visited node: create its children
+            const int to_move = (root_player + depth) & 1; // the player who moves INTO the children
+            if (C0[node] == NONE32) { // first descent through a visited node: create its children, shuffled
                 const int n = az_count_legal<GAME>(s, geom);
                 if (alloc + (uint32_t)n > p.uct_cap) return -1;
                 C0[node] = alloc;
-                META[node] = (META[node] & 0xFFFFu) | ((uint32_t)n << 16);
+                META[node] = (META[node] & 0xFF00FFFFu) | ((uint32_t)n << 16);
                 for (int k = 0; k < n; k++) {
                     N[alloc + k] = 0;
                     W[alloc + k] = 0.0;
                     C0[alloc + k] = NONE32;
                     META[alloc + k] = (uint32_t)az_nth_legal<GAME>(s, geom, k);
                 }
+                for (int i = n - 1; i >= 1; i--) { // random_state.shuffle
+                    int j = (int)(philox_u01(r) * (double)(i + 1));
+                    j = j > i ? i : j;
+                    const uint32_t t = META[alloc + i];
+                    META[alloc + i] = META[alloc + j];
+                    META[alloc + j] = t;
+                }
                 alloc += (uint32_t)n;
             }
             const uint32_t c0 = C0[node];
-            const int nc = (int)(META[node] >> 16);
+            const int nc = UCT_NCH(META[node]);
             const double L = p.log_table[N[node]];
             double best = -INFINITY;
             int bi = 0;
             for (int k = 0; k < nc; k++) {
                 const uint32_t cn = N[c0 + k];
-                const double v = cn == 0 ? INFINITY : W[c0 + k] / (double)cn + p.opp_c * sqrt(L / (double)cn);
+                const int oc = UCT_OUT(META[c0 + k]);
+                const double v = oc ? (to_move == 0 ? (double)(oc - 2) : -(double)(oc - 2))
+                                    : (cn == 0 ? INFINITY : W[c0 + k] / (double)cn + p.opp_c * sqrt(L / (double)cn));
                 if (v > best) {
                     best = v;
                     bi = k;
@@ -1176,28 +1193,58 @@ template <int GAME> __device__ int uct_search(const Params &p, int g, const AzSt
             term = az_apply<GAME>(s, geom, (int)(META[node] & 0xFFFFu), &ret0);
             path[++depth] = node;
         }
+        bool solved = false;
+        if (term) { // a terminal node takes its returns as outcome
+            META[node] = (META[node] & 0xF8FFFFFFu) | ((uint32_t)((int)ret0 + 2) << 24);
+            solved = true;
+        }
         while (!term) { // RandomRolloutEvaluator(1): uniformly random legal actions to the end of the game
             const int n = az_count_legal<GAME>(s, geom);
             int k = (int)(philox_u01(r) * (double)n);
             k = k < n ? k : n - 1;
             term = az_apply<GAME>(s, geom, az_nth_legal<GAME>(s, geom, k), &ret0);
         }
-        for (int d = 0; d <= depth; d++) { // the node at depth d was entered by player (root_player + d + 1) & 1
-            const int mover = (root_player + d + 1) & 1;
-            N[path[d]] += 1;
-            W[path[d]] += mover == 0 ? (double)ret0 : -(double)ret0;
+        for (int d = depth; d >= 0; d--) { // the node at depth d >= 1 was entered by player (root_player + d + 1) & 1; the root
+                                           // carries the player to move
+            const int mover = d == 0 ? root_player : (root_player + d + 1) & 1;
+            const uint32_t nd = path[d];
+            N[nd] += 1;
+            W[nd] += mover == 0 ? (double)ret0 : -(double)ret0;
+            if (solved && C0[nd] != NONE32) { // MCTS-Solver backup
+                const int player = (root_player + d) & 1; // the player to move at nd
+                const uint32_t c0 = C0[nd];
+                const int nc = UCT_NCH(META[nd]);
+                int best_oc = 0, best_v = -2;
+                bool all_solved = true;
+                for (int k = 0; k < nc; k++) {
+                    const int oc = UCT_OUT(META[c0 + k]);
+                    if (!oc) all_solved = false;
+                    else {
+                        const int vc = player == 0 ? oc - 2 : 2 - oc;
+                        if (vc > best_v) {
+                            best_v = vc;
+                            best_oc = oc;
+                        }
+                    }
+                }
+                if (best_oc && (all_solved || best_v == 1)) META[nd] = (META[nd] & 0xF8FFFFFFu) | ((uint32_t)best_oc << 24);
+                else solved = false;
+            }
         }
+        if (UCT_OUT(META[0])) break; // the root is solved
     }
     if (C0[0] == NONE32) return -1;
     const uint32_t c0 = C0[0];
-    const int nc = (int)(META[0] >> 16);
-    uint32_t bn = 0;
-    int bi = 0;
-    for (int k = 0; k < nc; k++)
-        if (k == 0 || N[c0 + k] > bn) {
-            bn = N[c0 + k];
+    const int nc = UCT_NCH(META[0]);
+    int bi = -1, bo = 0;
+    for (int k = 0; k < nc; k++) { // largest (proven outcome for the mover or 0, explore_count, total_reward); first maximum
+        const int oc = UCT_OUT(META[c0 + k]);
+        const int o = oc ? (root_player == 0 ? oc - 2 : 2 - oc) : 0;
+        if (bi < 0 || o > bo || (o == bo && (N[c0 + k] > N[c0 + bi] || (N[c0 + k] == N[c0 + bi] && W[c0 + k] > W[c0 + bi])))) {
             bi = k;
+            bo = o;
         }
+    }
     return (int)(META[c0 + bi] & 0xFFFFu);
 }
 

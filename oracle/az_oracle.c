@@ -789,13 +789,25 @@ typedef struct uct_node {
     int64_t explore_count;
     double total_reward; /* seen by the player who moved into this node */
     int action, n_children;
-    struct uct_node *children; /* created the first time a visited node is descended through */
+    int solved;          /* MCTS-Solver: the game-theoretic value below this node is known ... */
+    double outcome0;     /* ... and this is player 0's return under it */
+    struct uct_node *children; /* created the first time a visited node is descended through, in SHUFFLED legal-action order */
 } uct_node;
 static void uct_free(uct_node *n) {
     for (int i = 0; i < n->n_children; i++) uct_free(&n->children[i]);
     free(n->children);
 }
-/* MCTSBot.step: max_search_nodes simulations of UCT with one random rollout per new node; most visited root child */
+/* MCTSBot.step as OpenSpiel publishes it (open_spiel/python/algorithms/mcts.py; third party, absent here, restated: "parity
+ * unpinned"), with its defaults solve=True and child_selection_fn=SearchNode.uct_value:
+ *   tree policy   descend while the node has been visited; a visited node without children gets them on the way through, in
+ *                 an order SHUFFLED by the bot's random state (here: Fisher-Yates on the Philox stream);
+ *                 child value = its proven outcome for the player who moved into it, else +inf when unvisited, else
+ *                 total_reward / explore_count + uct_c * sqrt(log(parent explore_count) / explore_count); first maximum;
+ *   evaluation    a terminal node gets its returns as outcome (solved); any other leaf ONE uniformly random rollout;
+ *   backup        reward and count along the path; while "solved": a node whose children are all solved, or one of whose
+ *                 children is a proven win for the player to move, takes the outcome of its best child; else solved ends;
+ *   stop          after max_simulations, or as soon as the root is solved;
+ *   move          the child with the largest (proven outcome for the mover or 0, explore_count, total_reward); first maximum. */
 static int uct_bot_action(const orc_state *root_state, int n_sims, double uct_c, orc_philox *r) {
     uct_node root;
     memset(&root, 0, sizeof root);
@@ -807,9 +819,17 @@ static int uct_bot_action(const orc_state *root_state, int n_sims, double uct_c,
         int depth = 0;
         path[0] = node;
         while (!s.terminal && node->explore_count > 0) {
+            const int to_move = (root_player + depth) & 1; /* the player who moves INTO the children */
             if (!node->children) {
                 int32_t legal[ORC_MAX_CELLS * 3];
                 int n = orc_legal_actions(&s, legal);
+                for (int i = n - 1; i >= 1; i--) { /* random_state.shuffle */
+                    int j = (int)(philox_u01(r) * (double)(i + 1));
+                    if (j > i) j = i;
+                    int32_t t = legal[i];
+                    legal[i] = legal[j];
+                    legal[j] = t;
+                }
                 node->children = (uct_node *)calloc((size_t)n, sizeof(uct_node));
                 node->n_children = n;
                 for (int k = 0; k < n; k++) node->children[k].action = legal[k];
@@ -818,7 +838,8 @@ static int uct_bot_action(const orc_state *root_state, int n_sims, double uct_c,
             int bi = 0;
             for (int k = 0; k < node->n_children; k++) {
                 const uct_node *c = &node->children[k];
-                double v = c->explore_count == 0
+                double v = c->solved ? (to_move == 0 ? c->outcome0 : -c->outcome0)
+                           : c->explore_count == 0
                                ? INFINITY
                                : c->total_reward / (double)c->explore_count + uct_c * sqrt(L / (double)c->explore_count);
                 if (v > best) {
@@ -830,17 +851,52 @@ static int uct_bot_action(const orc_state *root_state, int n_sims, double uct_c,
             orc_apply_action(&s, node->action);
             path[++depth] = node;
         }
+        int solved = 0;
+        if (s.terminal) {
+            path[depth]->solved = 1;
+            path[depth]->outcome0 = s.ret0;
+            solved = 1;
+        }
         while (!s.terminal) orc_apply_action(&s, random_legal_action(&s, r)); /* RandomRolloutEvaluator(1) */
-        for (int d = 0; d <= depth; d++) {
-            int mover = (root_player + d + 1) & 1;
-            path[d]->explore_count += 1;
-            path[d]->total_reward += mover == 0 ? s.ret0 : -s.ret0;
+        for (int d = depth; d >= 0; d--) {
+            /* node at depth d >= 1 was entered by player (root_player + d - 1) & 1; the root carries the player to move */
+            int mover = d == 0 ? root_player : (root_player + d + 1) & 1;
+            uct_node *nd = path[d];
+            nd->explore_count += 1;
+            nd->total_reward += mover == 0 ? s.ret0 : -s.ret0;
+            if (solved && nd->children) {
+                const int player = (root_player + d) & 1; /* the player to move at nd */
+                const uct_node *bst = NULL;
+                int all_solved = 1;
+                for (int k = 0; k < nd->n_children; k++) {
+                    const uct_node *c = &nd->children[k];
+                    if (!c->solved) all_solved = 0;
+                    else {
+                        double vc = player == 0 ? c->outcome0 : -c->outcome0;
+                        if (!bst || vc > (player == 0 ? bst->outcome0 : -bst->outcome0)) bst = c;
+                    }
+                }
+                if (bst && (all_solved || (player == 0 ? bst->outcome0 : -bst->outcome0) == 1.0)) {
+                    nd->solved = 1;
+                    nd->outcome0 = bst->outcome0;
+                } else solved = 0;
+            }
+        }
+        if (root.solved) break;
+    }
+    int bi = -1;
+    double bo = 0;
+    for (int k = 0; k < root.n_children; k++) {
+        const uct_node *c = &root.children[k];
+        double o = c->solved ? (root_player == 0 ? c->outcome0 : -c->outcome0) : 0.0;
+        if (bi < 0 || o > bo || (o == bo && (c->explore_count > root.children[bi].explore_count ||
+                                              (c->explore_count == root.children[bi].explore_count &&
+                                               c->total_reward > root.children[bi].total_reward)))) {
+            bi = k;
+            bo = o;
         }
     }
-    int bi = 0;
-    for (int k = 1; k < root.n_children; k++)
-        if (root.children[k].explore_count > root.children[bi].explore_count) bi = k;
-    int action = root.n_children ? root.children[bi].action : -1;
+    int action = bi >= 0 ? root.children[bi].action : -1;
     uct_free(&root);
     return action;
 }
