@@ -339,3 +339,21 @@ def test_bench_host_core_detection_respects_the_cgroup_quota(tmp_path, monkeypat
     assert isinstance(bench.cpu_model(), str) and bench.cpu_model()
     assert bench.net_flops_per_eval(6, 7, 7, 10) == 36111600      # 36.1 MFLOP for the 10-block connect_four net
     assert abs(bench.tree_bytes_per_sim(6.5, 7, 7, 7, 6, 7) - 1722) < 1   # ... and its ~1.7 kB per sim
+
+
+def test_bench_reads_hbm_traffic_only_from_a_summary_of_the_same_workload():
+    """bench.py cannot collect PMC counters itself: `roofline.traffic` comes from the committed rocprofv3 summary, and only when
+    that summary was taken on the workload being run (its `# workload_key:` line) - otherwise null, never another run's bytes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    key = bench.workload_key("connect_four", 4096, 400, 10, 50, "fused", "random", "f32x", 1, 16)
+    net, tree = bench.pmc_traffic(key)
+    assert net is not None and tree is not None
+    # the tower writes its output in hi and lo halves (2 x 4096 x 42 x 64 x 2 B = 44 MB) and the head reads it back
+    assert 60e6 < net < 200e6 and 5e6 < tree < 30e6
+    for other in (bench.workload_key("connect_four", 4096, 400, 10, 50, "fused", "random", "f16", 1, 16),
+                  bench.workload_key("connect_four", 2048, 400, 10, 50, "fused", "random", "f32x", 1, 16),
+                  bench.workload_key("connect_four", 4096, 400, 10, 50, "fused", "random", "f32x", 2, 16)):
+        assert bench.pmc_traffic(other) == (None, None)
