@@ -22,5 +22,5 @@ struct HeadParams {
 hipError_t az_launch_tower_f16(int device, int nt, int ck, int waves, int r3, const TowerParams &tp, int grid, int lds, hipStream_t st);
 hipError_t az_launch_tower_x3(int device, int nt, bool rp1, int r3, const TowerParams &tp, int grid, int lds, hipStream_t st);
 hipError_t az_launch_tower_x3b(int device, const TowerParams &tp, int grid, hipStream_t st); // row-pair boards, <= 50 filters
-hipError_t az_launch_tower_x3c(int device, const TowerParams &tp, int grid, hipStream_t st); // the same, one board per workgroup (small batches)
+hipError_t az_launch_tower_x3c(int device, int bpw, const TowerParams &tp, int n_boards, hipStream_t st); // the same, a board per four waves, bpw boards per workgroup
 hipError_t az_launch_head(int device, bool x3, const HeadParams &hp, int n_boards, int lds_head, float *logits, hipStream_t st);

@@ -225,6 +225,7 @@ static void build_x3b_stream(const uint16_t *hi, const uint16_t *lo, int n_convs
 }
 
 #define AZ_X3C_MAX_BOARDS 512 // (set from profiles/r3_tower_vs_boards.txt)
+#define AZ_X3C_ONE_PER_WG 256 // up to here a board per workgroup fills fewer CUs than the chip has; above, two boards per workgroup (39 vs 49 us at 512 boards)
 // v_mfma instructions one wave (= one board) of az_tower_x3_kernel issues (az_tower_x3.h: 3 per product, every tile)
 static double x3_mfma_per_wave(int nt, int n_convs, int nks) { return 3.0 * (AZ_NET_K0STEPS + (double)(n_convs - 1) * nks) * 4 * nt; }
 
@@ -532,7 +533,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         tp.xout_lo = n->xout_lo;
         const int grid = (n_boards + 3) / 4;
         const bool x3c = n->x3b && n_boards <= AZ_X3C_MAX_BOARDS; // small batch: one board per workgroup (az_tower_x3c.h)
-        hipError_t s = x3c ? az_launch_tower_x3c(n->d.device, tp, n_boards, st)
+        hipError_t s = x3c ? az_launch_tower_x3c(n->d.device, n_boards > AZ_X3C_ONE_PER_WG ? 2 : 1, tp, n_boards, st)
                        : n->x3b ? az_launch_tower_x3b(n->d.device, tp, grid, st)
                               : az_launch_tower_x3(n->d.device, g.nt, g.rp1, n->r3, tp, grid, g.lds, st);
         if (s != hipSuccess) {

@@ -34,13 +34,16 @@ hipError_t az_launch_tower_x3b(int device, const TowerParams &tp, int grid, hipS
     return hipGetLastError();
 }
 
-hipError_t az_launch_tower_x3c(int device, const TowerParams &tp, int grid, hipStream_t st) {
+template <int BPW> static hipError_t launch_x3c(int device, const TowerParams &tp, int n_boards, hipStream_t st) {
     static bool attr_set[AZ_MAX_DEVICES] = {false};
     if (device < 0 || device >= AZ_MAX_DEVICES || !attr_set[device]) {
-        hipError_t s = hipFuncSetAttribute((const void *)az_tower_x3c_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t s = hipFuncSetAttribute((const void *)az_tower_x3c_kernel<3, BPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (s != hipSuccess) return s;
         if (device >= 0 && device < AZ_MAX_DEVICES) attr_set[device] = true;
     }
-    hipLaunchKernelGGL((az_tower_x3c_kernel<3>), dim3(grid), dim3(256), X3B::LDS, st, tp);
+    hipLaunchKernelGGL((az_tower_x3c_kernel<3, BPW>), dim3((n_boards + BPW - 1) / BPW), dim3(256 * BPW), X3B::LDS, st, tp);
     return hipGetLastError();
+}
+hipError_t az_launch_tower_x3c(int device, int bpw, const TowerParams &tp, int n_boards, hipStream_t st) {
+    return bpw == 2 ? launch_x3c<2>(device, tp, n_boards, st) : launch_x3c<1>(device, tp, n_boards, st);
 }

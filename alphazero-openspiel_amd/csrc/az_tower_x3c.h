@@ -28,25 +28,27 @@ template <bool IS_FIRST, int NT, bool TX> struct X3CK {
     static constexpr int n_b(int ks) { return mine(ks) ? K::n_b(ks) : 0; }
 };
 
-template <int NT>
-__global__ __launch_bounds__(256, 1) void az_tower_x3c_kernel(TowerParams p) {
+// BPW: boards per workgroup (1: four waves, one per SIMD; 2: eight waves - the two boards' waves of the same tile share a SIMD)
+template <int NT, int BPW>
+__global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int WAVES = 4, FR = X3B::FR, REC2 = X3B::REC2, CK = X3B::CK, NKS = X3B::NKS, PARTS = X3B::PARTS;
+    constexpr int WAVES = 4 * BPW, FR = X3B::FR, REC2 = X3B::REC2, CK = X3B::CK, NKS = X3B::NKS, PARTS = X3B::PARTS;
     constexpr int CHUNK_S = X3B::CHUNK_S, LO_OFF = X3B::LO_OFF, S_PLANE = X3B::S_PLANE;
     constexpr float INV_SPLIT = 1.0f / 2048.0f, SPLIT = 2048.0f;
     constexpr int plane_b = X3B::PLANE_B;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l15 = lane & 15;
-    const int board0 = blockIdx.x;     // one board per workgroup
-    const int region = X3B::OFF_ACT;   // (the planes of x3b's wave 0)
+    const int bl = wave >> 2, role = wave & 3, tid_b = tid & 255; // board of the workgroup, role in the board, thread in the board's four waves
+    const int board0 = blockIdx.x * BPW + bl;
+    const int region = X3B::OFF_ACT + bl * 2 * LO_OFF; // (x3b's map: planes of its wave bl, scratch of its wave bl)
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
-    const int trash = X3B::OFF_EPI + 2048 + tid * 16;
-    const int s_wave = X3B::OFF_S;
+    const int trash = X3B::OFF_EPI + 2048 + tid_b * 16; // (dump slots: two boards' threads may share one)
+    const int s_wave = X3B::OFF_S + bl * X3B::S_WAVE;
 
     { // zero the planes and the scratch, the four waves together
         uint4 z = {0, 0, 0, 0};
-        for (int i = tid * 16; i < 2 * LO_OFF; i += 256 * 16) *(uint4 *)(lds + region + i) = z;
-        for (int i = tid * 16; i < X3B::S_WAVE; i += 256 * 16) *(uint4 *)(lds + s_wave + i) = z;
+        for (int i = tid_b * 16; i < 2 * LO_OFF; i += 256 * 16) *(uint4 *)(lds + region + i) = z;
+        for (int i = tid_b * 16; i < X3B::S_WAVE; i += 256 * 16) *(uint4 *)(lds + s_wave + i) = z;
     }
     TowerTables<NT, true, true> T;
     T.init(p, region, plane_b, lds_base, board0, q, l15);
@@ -259,7 +261,8 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3c_kernel(TowerParams p) {
                         constexpr int r = RPS * j + decltype(rr_c)::value;
                         if constexpr (r < n_next) next_read(std::integral_constant<int, r>{});
                     });
-                    if constexpr (!TX && d >= 0 && j % 3 == 2 && 3 * d + j / 3 < 8) issue_piece(chunk_t, std::integral_constant<int, part_t>{}, 3 * d + j / 3);
+                    if constexpr (!TX && d >= 0 && j % 3 == 2 && 3 * d + j / 3 < (30 + WAVES - 1) / WAVES)
+                        issue_piece(chunk_t, std::integral_constant<int, part_t>{}, 3 * d + j / 3);
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
                     auto b_hi = [&](auto nt_c) -> half8 {
@@ -405,8 +408,8 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3c_kernel(TowerParams p) {
         conv_step(0, koff0, std::true_type{});
         for (int conv = 1; conv < p.n_convs; conv++) conv_step(conv, koff, std::false_type{});
     };
-    if (wave == 0) body(std::integral_constant<int, 0>{});
-    else if (wave == 1) body(std::integral_constant<int, 1>{});
-    else if (wave == 2) body(std::integral_constant<int, 2>{});
+    if (role == 0) body(std::integral_constant<int, 0>{});
+    else if (role == 1) body(std::integral_constant<int, 1>{});
+    else if (role == 2) body(std::integral_constant<int, 2>{});
     else body(std::integral_constant<int, 3>{});
 }
