@@ -3,6 +3,20 @@
 #pragma once
 #include "az_head_params.h"
 
+// The A operand of fc1 is 16 boards x 32 k per k-step, and the MFMA wants board l15's octet q in lane 16 q + l15.  Loaded that way,
+// the four neighbouring lanes of a load touch four different boards' rows: the texture addresser takes the 64 lanes as 64 separate
+// 16-byte accesses (rocprof, 6x6 logits kernel: 40 accesses per vector-memory instruction, the addresser busy 68 % of the kernel).
+// So lane L LOADS octet L & 3 of board L >> 2 - four neighbouring lanes = 64 contiguous bytes, 16 accesses per instruction - and
+// one ds_bpermute per dword then hands lane 16 q + r the registers of lane 4 r + q (no LDS memory involved).
+__device__ __forceinline__ half8 frag_from_rows(half8 v, int lane) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int src = (4 * (lane & 15) + (lane >> 4)) * 4;
+    i32x4 u = __builtin_bit_cast(i32x4, v);
+#pragma unroll
+    for (int i = 0; i < 4; i++) u[i] = __builtin_amdgcn_ds_bpermute(src, u[i]);
+    return __builtin_bit_cast(half8, u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // fc1 + softmax + tanh (network.py:61-64).  One workgroup = 16 boards; the K = HW*64 reduction is split
 // over the 4 waves (k-step ks goes to wave ks & 3), partial tiles are summed through LDS.
@@ -11,13 +25,13 @@ template <bool X3> __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kerne
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float *part = (float *)lds;                               // [HEAD_NW waves][OTG][64 lanes][4]
     float *logits = (float *)(lds + HEAD_NW * OTG * 64 * 16); // [16][n_ot*16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l15 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * 16;
     const int K = p.HW * AZ_NET_XOUT_C, NP = p.n_ot * 16;
-    int row = b0 + l15;
+    int row = b0 + (lane >> 2); // (load mapping of frag_from_rows)
     if (row >= p.n_boards) row = p.n_boards - 1; // clamp: computed, never stored
-    const _Float16 *xrow = p.x + (size_t)row * K + 8 * q;
-    const _Float16 *xrow_lo = X3 ? p.x_lo + (size_t)row * K + 8 * q : nullptr;
+    const _Float16 *xrow = p.x + (size_t)row * K + 8 * (lane & 3);
+    const _Float16 *xrow_lo = X3 ? p.x_lo + (size_t)row * K + 8 * (lane & 3) : nullptr;
     for (int og = 0; og < p.n_ot; og += OTG) {
         f32x4 acc[OTG], acc2[X3 ? OTG : 1];
 #pragma unroll
@@ -28,11 +42,11 @@ template <bool X3> __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kerne
                            // k-step; unrolled so that the loads of several k-steps are in flight together
 #pragma unroll 8
             for (int ks = wave; ks < p.ksteps; ks += HEAD_NW) {
-                half8 a = *(const half8 *)(xrow + 32 * ks);
+                half8 a = frag_from_rows(*(const half8 *)(xrow + 32 * ks), lane);
                 half8 w = *(const half8 *)(p.fc_w + ((size_t)ks * 64 + lane) * 8);
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w, acc[0], 0, 0, 0);
                 if constexpr (X3) {
-                    half8 al = *(const half8 *)(xrow_lo + 32 * ks);
+                    half8 al = frag_from_rows(*(const half8 *)(xrow_lo + 32 * ks), lane);
                     half8 wl = *(const half8 *)(p.fc_w_lo + ((size_t)ks * 64 + lane) * 8);
                     acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wl, acc2[0], 0, 0, 0);
                     acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, w, acc2[0], 0, 0, 0);
@@ -40,9 +54,9 @@ template <bool X3> __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kerne
             }
         } else
         for (int ks = wave; ks < p.ksteps; ks += HEAD_NW) {
-            half8 a = *(const half8 *)(xrow + 32 * ks);
+            half8 a = frag_from_rows(*(const half8 *)(xrow + 32 * ks), lane);
             half8 al;
-            if constexpr (X3) al = *(const half8 *)(xrow_lo + 32 * ks);
+            if constexpr (X3) al = frag_from_rows(*(const half8 *)(xrow_lo + 32 * ks), lane);
 #pragma unroll
             for (int o = 0; o < OTG; o++)
                 if (og + o < p.n_ot) {
@@ -131,10 +145,10 @@ template <bool X3, int HEAD_MT> __global__ __launch_bounds__(256) void az_head_l
     const _Float16 *xrow[HEAD_MT], *xrow_lo[HEAD_MT];
 #pragma unroll
     for (int m = 0; m < HEAD_MT; m++) {
-        int row = b0 + 16 * m + l15;
+        int row = b0 + 16 * m + (lane >> 2); // (load mapping of frag_from_rows)
         if (row >= p.n_boards) row = p.n_boards - 1; // clamp: computed, never stored
-        xrow[m] = p.x + (size_t)row * K + 8 * q;
-        xrow_lo[m] = X3 ? p.x_lo + (size_t)row * K + 8 * q : nullptr;
+        xrow[m] = p.x + (size_t)row * K + 8 * (lane & 3);
+        xrow_lo[m] = X3 ? p.x_lo + (size_t)row * K + 8 * (lane & 3) : nullptr;
     }
     half8 a[HEAD_RING][CK][HEAD_MT], al[HEAD_RING][X3 ? CK : 1][X3 ? HEAD_MT : 1];
     // chunk c -> LDS slot `slot` (compile-time) + the A fragments of its k-steps.  Out-of-range tiles / k-steps re-fetch a valid
@@ -173,6 +187,11 @@ template <bool X3, int HEAD_MT> __global__ __launch_bounds__(256) void az_head_l
             }
         }
     };
+    // The biases come in HERE.  vmcnt counts stores too on this chip: a bias load between the output tiles' stores waited for the
+    // stores before it - four store round trips in a row, 65 % of the kernel (clock64 probes, 6x6).
+    float bias_o[HEAD_OTG];
+#pragma unroll
+    for (int o = 0; o < HEAD_OTG; o++) bias_o[o] = p.fc_b[16 * (og + o < p.n_ot ? og + o : p.n_ot - 1) + l15];
     f32x4 acc[HEAD_MT][HEAD_OTG], acc2[X3 ? HEAD_MT : 1][X3 ? HEAD_OTG : 1];
 #pragma unroll
     for (int m = 0; m < HEAD_MT; m++)
@@ -200,25 +219,40 @@ template <bool X3, int HEAD_MT> __global__ __launch_bounds__(256) void az_head_l
                 asm volatile("" ::: "memory");
                 if (c + HEAD_RING - 1 < n_chunks) issue_chunk(c + HEAD_RING - 1, std::integral_constant<int, (slot + HEAD_RING - 1) % HEAD_RING>{});
                 const unsigned char *wb = lds + slot * CHUNK_B + lane * 16;
+                // One straight-line block per chunk: the A fragments' lane exchange and ALL the chunk's weight-fragment reads go out first,
+                // the MFMAs follow behind counted waits (a branch per k-step left each k-step waiting out two LDS round trips).  A k-step
+                // past the end (odd H*W only) multiplies a zero A fragment.
+                half8 af[CK][HEAD_MT], afl[X3 ? CK : 1][X3 ? HEAD_MT : 1];
+                half8 w[CK][HEAD_OTG], wl[X3 ? CK : 1][X3 ? HEAD_OTG : 1];
+                const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int ksl = 0; ksl < CK; ksl++) {
-                    if (c * CK + ksl < p.ksteps) {
+                    const bool live = c * CK + ksl < p.ksteps;
 #pragma unroll
-                        for (int o = 0; o < HEAD_OTG; o++) {
-                            const half8 w = *(const half8 *)(wb + (ksl * HEAD_OTG + o) * 1024);
-                            half8 wl;
-                            if constexpr (X3) wl = *(const half8 *)(wb + ((CK + ksl) * HEAD_OTG + o) * 1024);
-#pragma unroll
-                            for (int m = 0; m < HEAD_MT; m++) {
-                                acc[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[slot][ksl][m], w, acc[m][o], 0, 0, 0);
-                                if constexpr (X3) {
-                                    acc2[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[slot][ksl][m], wl, acc2[m][o], 0, 0, 0);
-                                    acc2[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[slot][ksl][m], w, acc2[m][o], 0, 0, 0);
-                                }
-                            }
-                        }
+                    for (int m = 0; m < HEAD_MT; m++) {
+                        af[ksl][m] = frag_from_rows(live ? a[slot][ksl][m] : zero8, lane);
+                        if constexpr (X3) afl[ksl][m] = frag_from_rows(live ? al[slot][ksl][m] : zero8, lane);
                     }
                 }
+#pragma unroll
+                for (int ksl = 0; ksl < CK; ksl++)
+#pragma unroll
+                    for (int o = 0; o < HEAD_OTG; o++) {
+                        w[ksl][o] = *(const half8 *)(wb + (ksl * HEAD_OTG + o) * 1024);
+                        if constexpr (X3) wl[ksl][o] = *(const half8 *)(wb + ((CK + ksl) * HEAD_OTG + o) * 1024);
+                    }
+#pragma unroll
+                for (int ksl = 0; ksl < CK; ksl++)
+#pragma unroll
+                    for (int o = 0; o < HEAD_OTG; o++)
+#pragma unroll
+                        for (int m = 0; m < HEAD_MT; m++) {
+                            acc[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ksl][m], w[ksl][o], acc[m][o], 0, 0, 0);
+                            if constexpr (X3) {
+                                acc2[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ksl][m], wl[ksl][o], acc2[m][o], 0, 0, 0);
+                                acc2[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afl[ksl][m], w[ksl][o], acc2[m][o], 0, 0, 0);
+                            }
+                        }
             }
         });
     }
@@ -227,7 +261,7 @@ template <bool X3, int HEAD_MT> __global__ __launch_bounds__(256) void az_head_l
     for (int o = 0; o < HEAD_OTG; o++) {
         if (og + o >= p.n_ot) continue;
         const int col = 16 * (og + o) + l15;
-        const float bias = p.fc_b[col];
+        const float bias = bias_o[o];
 #pragma unroll
         for (int m = 0; m < HEAD_MT; m++) {
             f32x4 v = acc[m][o];

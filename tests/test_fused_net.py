@@ -48,6 +48,9 @@ def _nets():
                          Net([3, 5, 4], 240, n_blocks=3, n_filters=32).eval()),
         # > 50 filters: output-channel tile 3 is streamed in full (the <= 50 case streams 2 of its 16 rows)
         "c4_56f_2block": (c4, Net([3, 6, 7], 7, n_blocks=2, n_filters=56).eval()),
+        # 25 cells: 50 k-steps of fc1, not a whole number of the logits kernel's 4-k-step weight chunks
+        "bt5x5_2block": (games.load_game("breakthrough(rows=5,columns=5)"),
+                         Net([3, 5, 5], 300, n_blocks=2, n_filters=50).eval()),
         # 4 rows = 2 row-pair tiles per board: the 3-tile kernel must mask its third tile
         "bt4x5_2block": (games.load_game("breakthrough(rows=4,columns=5)"),
                          Net([3, 4, 5], 240, n_blocks=2, n_filters=40).eval()),
@@ -102,7 +105,7 @@ def test_net_matches_reference_golden_outputs():
 @pytest.mark.parametrize("tag,n", [("c4_ckpt", 24), ("c4_ckpt", 1), ("c4_ckpt", 157), ("bt6_ckpt", 40),
                                    ("c4_10block", 300), ("bt8_2block", 37), ("bt5x4_3block", 50),
                                    ("bt4x5_2block", 3), ("bt4x5_2block", 130), ("c4_10block", 4096),
-                                   ("c4_56f_2block", 33), ("c4_56f_2block", 2100),
+                                   ("c4_56f_2block", 33), ("c4_56f_2block", 2100), ("bt5x5_2block", 70),
                                    ("bt6_10block", 4096), ("bt8_20block", 2048)])
 def test_fused_forward_matches_torch(tag, n):
     game, net = _nets()[tag]
@@ -134,7 +137,7 @@ def test_fused_forward_matches_torch(tag, n):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,n", [("c4_ckpt", 157), ("c4_10block", 4096), ("bt6_ckpt", 40), ("bt6_10block", 4096),
                                    ("bt8_2block", 37), ("bt8_20block", 2048), ("bt5x4_3block", 50), ("bt4x5_2block", 130),
-                                   ("c4_56f_2block", 33)])
+                                   ("c4_56f_2block", 33), ("bt5x5_2block", 70)])
 def test_fused_f32x_forward_is_fp32_grade(tag, n):
     """precision="f32x" (AZ_NET_PREC_F16X3: split-fp16 operands, three MFMAs per product) against an fp64 evaluation of
     the same net: the error must be of the order of torch-fp32's own error against fp64 - i.e. the path is a stand-in
