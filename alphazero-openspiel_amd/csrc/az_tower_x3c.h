@@ -1,5 +1,6 @@
 // az_tower_x3c.h — az_tower_x3c_kernel: az_tower_x3b_kernel's arithmetic (fp32-grade, split-fp16 operands, no output-channel
-// tile for channels 48, 49) for SMALL batches: one board per WORKGROUP instead of one per wave.
+// tile for channels 48, 49) for SMALL batches: one board per FOUR waves instead of one per wave (a workgroup = one such board up
+// to 256 boards, two above: az_net.hip).
 // Reference computation: ResidualBlock.forward x n_blocks of Net.forward (network.py:48-64,99-104) in eval mode.
 //
 // With a board per wave a launch of <= 1024 boards is one round that lasts as long as ONE board's chain of 19+ convs
@@ -17,6 +18,9 @@
 // Every accumulator sees the same MFMAs in the same order as in az_tower_x3b_kernel and the epilogue arithmetic is the same
 // code, so a board's outputs are the same BITS whichever kernel evaluates it (tests/test_fused_net.py) - the records of a
 // generation cannot depend on when its tail switches kernels.
+// Two boards per workgroup (BPW = 2, eight waves): the waves of one role land on one SIMD and fill each other's waits; the boards
+// use the planes and scratch of x3b's waves 0 and 1, the barriers and the weight stream are the workgroup's.  512 boards: 49 -> 39 us
+// (3-block net); as a replacement for x3b at 4096 boards it loses (202 vs 173 us): the T + X wave's SIMD idles three quarters of the time.
 #pragma once
 #include "az_tower_x3b.h"
 
