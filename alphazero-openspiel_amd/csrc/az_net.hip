@@ -533,6 +533,16 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         tp.xout_lo = n->xout_lo;
         const int grid = (n_boards + 3) / 4;
         const bool x3c = n->x3b && n_boards <= AZ_X3C_MAX_BOARDS; // small batch: one board per workgroup (az_tower_x3c.h)
+        // ... and with a single output tile (connect_four: 7 + 1 outputs) that kernel also runs fc1 + softmax + tanh for its board:
+        // at <= 512 boards the head kernel is 7 us of a 49 us tick (profiles/r3_small_generation_kernel_stats.csv)
+        const bool fused_head = x3c && n->n_ot == 1 && hp.ksteps <= 96 && n->d.cols >= 4; // (eight chains x HMAX k-steps; a chain steps 4 columns: az_tower_x3c.h)
+        tp.fc_w = fused_head ? n->fc_w : nullptr;
+        tp.fc_w_lo = n->fc_w_lo;
+        tp.fc_b = n->fc_b;
+        tp.priors = priors;
+        tp.values = values;
+        tp.A = n->d.num_actions;
+        tp.fc_ksteps = hp.ksteps;
         hipError_t s = x3c ? az_launch_tower_x3c(n->d.device, n_boards > AZ_X3C_ONE_PER_WG ? 2 : 1, tp, n_boards, st)
                        : n->x3b ? az_launch_tower_x3b(n->d.device, tp, grid, st)
                               : az_launch_tower_x3(n->d.device, g.nt, g.rp1, n->r3, tp, grid, g.lds, st);
@@ -540,7 +550,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
             n->err = std::string("f16x3 tower launch: ") + hipGetErrorString(s);
             return AZ_E_HIP;
         }
-        NCHK(n, az_launch_head(n->d.device, true, hp, n_boards, n->lds_head, n->logits, st));
+        if (!fused_head) NCHK(n, az_launch_head(n->d.device, true, hp, n_boards, n->lds_head, n->logits, st));
         return AZ_OK;
     }
     const TowerGeom g = choose_geom(n, n_boards);
@@ -567,6 +577,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     tp.obs = obs;
     tp.xout = n->xout;
     tp.xout_lo = nullptr;
+    tp.fc_w = nullptr;
     int per_wg = g.waves * g.bpw, grid = (n_boards + per_wg - 1) / per_wg;
     hipError_t s = az_launch_tower_f16(n->d.device, g.nt, g.ck, g.waves, n->r3, tp, grid, g.lds, st);
     if (s != hipSuccess) {
