@@ -225,6 +225,7 @@ static void build_x3b_stream(const uint16_t *hi, const uint16_t *lo, int n_convs
 }
 
 #define AZ_X3C_MAX_BOARDS 512 // (set from profiles/r3_tower_vs_boards.txt)
+#define AZ_F16C_MAX_BOARDS 512 // the same for the f16 tower (az_tower_f16c.h)
 #define AZ_X3C_ONE_PER_WG 256 // up to here a board per workgroup fills fewer CUs than the chip has; above, two boards per workgroup (39 vs 49 us at 512 boards)
 // v_mfma instructions one wave (= one board) of az_tower_x3_kernel issues (az_tower_x3.h: 3 per product, every tile)
 static double x3_mfma_per_wave(int nt, int n_convs, int nks) { return 3.0 * (AZ_NET_K0STEPS + (double)(n_convs - 1) * nks) * 4 * nt; }
@@ -579,7 +580,19 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     tp.xout_lo = nullptr;
     tp.fc_w = nullptr;
     int per_wg = g.waves * g.bpw, grid = (n_boards + per_wg - 1) / per_wg;
-    hipError_t s = az_launch_tower_f16(n->d.device, g.nt, g.ck, g.waves, n->r3, tp, grid, g.lds, st);
+    hipError_t s;
+    // small batch of a row-pair board with <= 50 filters: a board per four-wave workgroup (az_tower_f16c.h; same bits)
+    const TowerGeom gc = tower_geom(1, 1, n->d.rows, n->d.cols);
+    if (n_boards <= AZ_F16C_MAX_BOARDS && n->r3 == 2 && gc.tpb && gc.rs == 8 && gc.tpb <= 3) {
+        // up to a board per CU: 32 KiB weight chunks (half the barriers); above: 16 KiB chunks, so that two workgroups fit a CU's LDS
+        const int ck = n_boards <= AZ_X3C_ONE_PER_WG ? 8 : 4;
+        tp.cells = gc.cells, tp.rs = gc.rs, tp.tpb = gc.tpb;
+        tp.off_epi = (ck == 8 ? 4 : 3) * ck * 4096; // a ring of four 32-KiB / three 16-KiB weight buffers (147 / 65 KB with the planes)
+        tp.off_act = tp.off_epi + 2048 + 8 * 64 * 8;
+        tp.bpw = 1, tp.rcells = gc.rcells, tp.zcell = gc.zcell;
+        s = az_launch_tower_f16c(n->d.device, ck, tp, n_boards, tp.off_act + N_OCT * gc.rcells * OCT_B, st);
+    } else
+        s = az_launch_tower_f16(n->d.device, g.nt, g.ck, g.waves, n->r3, tp, grid, g.lds, st);
     if (s != hipSuccess) {
         n->err = std::string("tower launch: ") + hipGetErrorString(s);
         return AZ_E_HIP;

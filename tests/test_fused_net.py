@@ -199,7 +199,7 @@ def test_fused_outputs_do_not_depend_on_the_batch_size():
     ref_p, ref_v = [t.clone() for t in fn.forward(obs)]
     torch.cuda.synchronize()
     ref_t = fn.read_tower(4096)
-    for n in (2048, 1024, 300, 64, 5):
+    for n in (2048, 1024, 513, 512, 300, 257, 256, 64, 5):   # (<= 512 / <= 256 boards: az_tower_f16c_kernel, 16- / 32-KiB weight chunks)
         p, v = fn.forward(obs[:n].contiguous())
         torch.cuda.synchronize()
         assert torch.equal(p, ref_p[:n]) and torch.equal(v, ref_v[:n]), n
