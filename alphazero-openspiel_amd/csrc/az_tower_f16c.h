@@ -15,8 +15,9 @@
 // Measured (256 boards, 10 blocks, tower + head): 62.8 -> 47 us; 512 boards (16-KiB chunks, two workgroups per CU) 66 -> 59 us.
 // The slope is 1.7 us per conv whatever was tried on the schedule - reads left to the compiler 47.3, hoisted 43.5-47, a four-deep
 // weight ring 45.6, one body for the four waves instead of four specialised copies 46.9, a per-workgroup rotation of the weight
-// pieces 47.6 (box-to-box noise is of that size): at a board per CU every workgroup streams ALL the weights, 49 KB per conv x 256
-// workgroups = 7.4 TB/s of L2 reads, the same ceiling the fc1 kernel of the breakthrough heads sits at.
+// pieces 47.6 (box-to-box noise is of that size).  Not a shared resource either: with half the workgroups (128 boards) the x3c
+// launch is 8 % shorter, and two boards per workgroup at 256 boards are slower (77 vs 65 us): it is one workgroup's own chain of
+// barriers, LDS round trips and dependent MFMAs per conv.
 #pragma once
 #include "az_tower_f16.h"
 
