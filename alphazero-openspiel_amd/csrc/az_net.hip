@@ -535,7 +535,9 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         const int grid = (n_boards + 3) / 4;
         const bool x3c = n->x3b && n_boards <= AZ_X3C_MAX_BOARDS; // small batch: one board per workgroup (az_tower_x3c.h)
         // ... and with a single output tile (connect_four: 7 + 1 outputs) that kernel also runs fc1 + softmax + tanh for its board:
-        // at <= 512 boards the head kernel is 7 us of a 49 us tick (profiles/r3_small_generation_kernel_stats.csv)
+        // at <= 512 boards the head kernel is 7 us of a 49 us tick (profiles/r3_small_generation_kernel_stats.csv).  (The same inside
+        // az_tower_x3b_kernel, measured: bit-identical and SLOWER - 1146 vs 1182 games/s in a same-box A/B: at one workgroup per CU
+        // the head phase of each of the four rounds, ~5 us, has nothing to hide behind.)
         const bool fused_head = x3c && n->n_ot == 1 && hp.ksteps <= 96 && n->d.cols >= 4; // (eight chains x HMAX k-steps; a chain steps 4 columns: az_tower_x3c.h)
         tp.fc_w = fused_head ? n->fc_w : nullptr;
         tp.fc_w_lo = n->fc_w_lo;

@@ -23,6 +23,7 @@
 // (3-block net); as a replacement for x3b at 4096 boards it loses (202 vs 173 us): the T + X wave's SIMD idles three quarters of the time.
 #pragma once
 #include "az_tower_x3b.h"
+#include "az_head_fused.h"
 
 // what a wave of az_tower_x3c_kernel reads for k-step ks (TX: the wave of tiles T and X, which multiplies only where they are on)
 template <bool IS_FIRST, int NT, bool TX> struct X3CK {
@@ -419,101 +420,11 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
     else if (role == 2) body(std::integral_constant<int, 2>{});
     else body(std::integral_constant<int, 3>{});
 
-    // ---- fc1 + softmax + tanh (network.py:61-64) for this board, when the net has a single output tile.  The arithmetic is
-    // az_head_kernel<true>'s, MFMA for MFMA: that kernel splits the K = H*W*64 reduction over eight waves (k-step ks goes to wave
-    // ks & 7) and adds the eight partial tiles in wave order; here the board's four waves run two of those chains each, with the
-    // board in EVERY row of the A operand (an MFMA row depends on that row's data only), and row 0 is what is kept - the same
-    // bits as the separate kernel (tests/test_fused_net.py: x3c against x3b + az_head_kernel).  A fragments come from the planes
-    // the last epilogue just wrote (octets 0-5 sixteen bytes per cell, channels 48, 49 from the compact plane, octet 7 zero).
+    // ---- fc1 + softmax + tanh for the workgroup's board(s), when the net has a single output tile (az_head_fused.h): the weight
+    // buffers are free now (every wave's last __syncthreads drained its LDS-DMA); one board: two chains per wave; two boards: one
+    // chain per wave for both (rows 0-7 / 8-15)
     if (p.fc_w) {
-        float *part = (float *)(lds + bl * 1024); // the weight buffers are free now: [8 chains][16 outputs] + 16 logits per board
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        constexpr int HMAX = 12; // k-steps per chain: ceil(2 * H * W / 8), boards of <= 48 cells
-        // A fragment of k-step ks = (cell ks >> 1, channel half ks & 1): a chain's k-steps are 8 apart, so the half - and with it this
-        // lane's octet o = 4 (ks & 1) + q and which of the three cases it reads - is fixed along the chain, and the cell moves 4 columns
-        // (one row wrap at most: W >= 4) per step.  Everything but the octet is wave-uniform: kept in scalar registers.
-        // BPW == 2: ONE chain per wave for BOTH boards - rows 0-7 of the A operand are the workgroup's first board, rows 8-15 its second
-        // (D rows 0 and 8 are kept) - so the 168 KiB of fc weights come in once per workgroup: through a CU's 64 B/clk vector-memory
-        // path they are 1.3 us per board streamed, as much as the MFMAs and the softmax together.
-        const int region_h = BPW == 2 ? X3B::OFF_ACT + (l15 >> 3) * 2 * LO_OFF : region;
-        auto a_frag = [&](int cell, int o, half8 &a, half8 &al) {
-            const unsigned char *s16 = lds + region_h + (o <= 5 ? o * plane_b + cell * 16 : 0);
-            const unsigned char *s4 = lds + region_h + (o == 6 ? 6 * plane_b + cell * 4 : 0);
-            const u32x4 r16 = *(const u32x4 *)s16, r16l = *(const u32x4 *)(s16 + LO_OFF);
-            const unsigned r4 = *(const unsigned *)s4, r4l = *(const unsigned *)(s4 + LO_OFF);
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            a = __builtin_bit_cast(half8, o <= 5 ? r16 : o == 6 ? (u32x4){r4, 0u, 0u, 0u} : z);
-            al = __builtin_bit_cast(half8, o <= 5 ? r16l : o == 6 ? (u32x4){r4l, 0u, 0u, 0u} : z);
-        };
-        const int last = p.fc_ksteps - 1;
-        const float bias_v = p.fc_b[lane & 15]; // (in flight behind the weight fragments; used after the barrier below)
-        // a chain's weight fragments all at once (one round trip to L2), then its MFMAs with the A fragments read one k-step ahead
-        auto load_chain = [&](int w, half8 (&wv)[HMAX], half8 (&wl)[HMAX]) {
-#pragma unroll
-            for (int i = 0; i < HMAX; i++) {
-                const int ks = w + 8 * i < last ? w + 8 * i : last; // (past the end: a valid fragment, never multiplied)
-                wv[i] = *(const half8 *)(p.fc_w + ((size_t)ks * 64 + lane) * 8);
-                wl[i] = *(const half8 *)(p.fc_w_lo + ((size_t)ks * 64 + lane) * 8);
-            }
-        };
-        auto run_chain = [&](int w_v, const half8 (&wv)[HMAX], const half8 (&wl)[HMAX]) {
-            const int w = __builtin_amdgcn_readfirstlane(w_v);
-            f32x4 ha = {0.f, 0.f, 0.f, 0.f}, ha2 = {0.f, 0.f, 0.f, 0.f};
-            const int o = 4 * (w & 1) + q;
-            int x = w >> 1, y = 0; // cell of k-step w (w < 8, W >= 4: row 0)
-            half8 a_nx, al_nx;
-            a_frag((y + 1) * p.rs + x + 1, o, a_nx, al_nx);
-#pragma unroll
-            for (int i = 0; i < HMAX; i++) {
-                const half8 a = a_nx, al = al_nx;
-                if (i + 1 < HMAX) {
-                    x += 4;
-                    if (x >= p.W) x -= p.W, y++;
-                    const int yc = y < p.H ? y : p.H - 1; // (past the end: any cell of the board, never multiplied)
-                    a_frag((yc + 1) * p.rs + x + 1, o, a_nx, al_nx);
-                }
-                if (w + 8 * i <= last) {
-                    ha = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wv[i], ha, 0, 0, 0);
-                    ha2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wl[i], ha2, 0, 0, 0);
-                    ha2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wv[i], ha2, 0, 0, 0);
-                }
-            }
-            ha = ha + ha2 * (1.0f / 2048.0f);
-            // D row 0 = lanes 0..15, element 0; row 8 = lanes 32..47, element 0; column = output l15
-            if (BPW == 1 ? lane < 16 : !(q & 1)) ((float *)(lds + (BPW == 1 ? bl : q >> 1) * 1024))[w * 16 + l15] = ha[0];
-        };
-        {
-            half8 wv0[HMAX], wl0[HMAX];
-            load_chain(BPW == 1 ? role : wave, wv0, wl0);
-            if constexpr (BPW == 1) { // 512 registers per lane: the second chain's fragments are in flight under the first chain's MFMAs
-                half8 wv1[HMAX], wl1[HMAX];
-                load_chain(role + 4, wv1, wl1);
-                run_chain(role, wv0, wl0);
-                run_chain(role + 4, wv1, wl1);
-            } else run_chain(wave, wv0, wl0);
-        }
-        __syncthreads();
-        if (role == 0) {
-            const int sub = lane & 15; // (lanes 16..63 repeat lanes 0..15 and store nothing)
-            float v = part[sub];
-#pragma unroll
-            for (int w = 1; w < 8; w++) v += part[w * 16 + sub];
-            float *lg = part + 128;
-            if (lane < 16) lg[sub] = v + bias_v;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (same wave: the stores are ordered before the loads below)
-            float mx = -INFINITY;
-            for (int o = sub; o < p.A; o += 16) mx = fmaxf(mx, lg[o]);
-#pragma unroll
-            for (int off = 8; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
-            float sum = 0.f;
-            for (int o = sub; o < p.A; o += 16) sum += expf(lg[o] - mx);
-#pragma unroll
-            for (int off = 8; off; off >>= 1) sum += __shfl_xor(sum, off, 16);
-            if (lane < 16 && board0 < p.n_boards) {
-                float *out = p.priors + (size_t)board0 * p.A;
-                for (int o = sub; o < p.A; o += 16) out[o] = expf(lg[o] - mx) / sum;
-                if (sub == 0) p.values[board0] = tanhf(lg[p.A]);
-            }
-        }
+        if constexpr (BPW == 1) x3_fused_head<4, 4, true>(p, lds, lds, region, 0, plane_b, LO_OFF, lane, role, role == 0 ? 0 : -1, board0);
+        else x3_fused_head<3, 8, false>(p, lds, lds, X3B::OFF_ACT, 2 * LO_OFF, plane_b, LO_OFF, lane, wave, role == 0 ? bl : -1, board0);
     }
 }
