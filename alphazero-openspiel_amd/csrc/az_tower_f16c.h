@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_f16c_kernel(TowerParams p) {
     constexpr int REC = WRec<R3>::BYTES, ROWS = WRec<R3>::ROWS;
     constexpr int CHUNK_B = CK * REC, CHUNK_S = CK * 4 * 64 * 16;
     constexpr int PARTS = (NKS + CK - 1) / CK, C0_B = AZ_NET_K0STEPS * REC;
-    static_assert(PARTS >= 2, "the epilogue parameters of a conv land behind its second chunk barrier");
+    static_assert(PARTS >= 2, "a conv's epilogue parameters are requested one conv = at least two chunk steps ahead (see the order of issue below)");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l15 = lane & 15;
     const int plane_b = p.rcells * OCT_B, region_b = N_OCT * plane_b;
