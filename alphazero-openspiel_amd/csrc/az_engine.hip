@@ -427,12 +427,10 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, b
         }
         st_compact++;
         if (rsv_np >= 0) {
-            // queue the copy for the extra workgroups of the NEXT tick's launch (compact_jobs: a workgroup per job; it writes
-            // alloc[g]); nothing in the rest of this tick touches the tree, the slot sits the next tick out (PH_COMPACTING, set
-            // by the caller) and then finds its tree at node 0 of the new pool
+            // the copy goes to the extra workgroups of THIS launch (compact_jobs: a workgroup per job; it writes alloc[g]).  The
+            // caller publishes the job once the slot's state is stored (move_step); nothing in the rest of this tick touches the
+            // tree, and the next tick finds it at node 0 of the new pool
             if (lane == 0) {
-                const int j = atomicAdd(p.cjob_count + p.cj_parity, 1);
-                p.cjob_list[(size_t)p.cj_parity * p.G + j] = g;
                 p.cj_from[g] = sr.pool;
                 p.cj_entry[g] = k;
                 p.cj_root[g] = sr.root;
@@ -454,22 +452,42 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, b
     }
 }
 
-// Deferred compaction: the last AZ_COMPACT_WGS workgroups of a tick kernel launch work off the jobs the launch BEFORE queued
-// (list 1 - cj_parity), beside the slots' own waves - the queued slots sit this tick out.  One 256-thread workgroup per job copies
-// the subtree under cj_root[g] of pool cj_from[g] into the slot's new pool, breadth first, 256 parents per round: the children of a
-// round are numbered by a block-wide prefix sum (the SAME order - hence the same node indices - as compact_subtree's wave-wide
-// one) and copied one node per thread and step, so a round is two or three memory round trips whatever the fan-out.  The last
-// workgroup to finish clears the list.  (It was a kernel of its own for a day: 4.9 us per tick, empty or not.)
+// Handed-over compaction: the last AZ_COMPACT_WGS workgroups of a tick kernel launch take the jobs the slot waves of the SAME launch
+// publish (move_step: the slot's state is stored, then its index goes into cjob_list with release semantics), beside the other slots'
+// playouts.  One 256-thread workgroup per job copies the subtree under cj_root[g] of pool cj_from[g] into the slot's new pool,
+// breadth first, 256 parents per round: the children of a round are numbered by a block-wide prefix sum (the SAME order - hence
+// the same node indices - as compact_subtree's wave-wide one) and copied one node per thread and step, so a round is two or three
+// memory round trips whatever the fan-out.  Workgroup w takes positions w, w + n_wg, ... of the list; an empty position is polled
+// until it fills or every slot wave of the launch has counted itself out (cjob_count[1] == n_slot_waves: nobody can publish any
+// more), so the launch ends with every job done and a slot never carries a pending copy across launches - a captured graph may
+// hold any number of launches, and the other entry points (advance_slots, read_tree, ...) never meet a half-copied pool.  The last
+// workgroup out clears the counters.  (The copies ran in a kernel of their own for a day: 4.9 us per tick, empty or not; then in
+// the NEXT launch, keyed by a host-side parity that a graph of an odd number of launches froze: ADVICE r3.)
 #define CJ_THREADS 256
 #define AZ_COMPACT_WGS 64 // extra workgroups per launch (jobs are rare; a burst is worked off 64 at a time)
-__device__ void compact_jobs(const Params &p, const int wg, const int n_wg) {
+__device__ void compact_jobs(const Params &p, const int wg, const int n_wg, const int n_slot_waves) {
     __shared__ uint32_t sh_off[CJ_THREADS + 1], sh_c0[CJ_THREADS];
     __shared__ int sh_wave[CJ_THREADS / 64];
+    __shared__ int sh_g;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int par = 1 - p.cj_parity;
-    const int n_jobs = p.cjob_count[par];
-    for (int job = wg; job < n_jobs; job += n_wg) {
-        const int g = p.cjob_list[(size_t)par * p.G + job];
+    for (int job = wg; job < p.G; job += n_wg) {
+        if (tid == 0) {
+            int g = -1;
+            bool over = false;
+            for (int spin = 0; spin < (1 << 22); spin++) { // (bounded: ~a second; a launch lasts tens of microseconds)
+                g = __hip_atomic_load(p.cjob_list + job, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (g >= 0 || over) break;
+                // every publish precedes its wave's count: once all waves are counted, one more look at the position settles it
+                over = __hip_atomic_load(p.cjob_count + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= n_slot_waves;
+                if (!over) __builtin_amdgcn_s_sleep(16);
+            }
+            if (g < 0 && !over) atomicOr(p.faults, AZ_FAULT_POOL_EXHAUSTED); // (the slot waves never finished: wedged device)
+            sh_g = g;
+        }
+        __syncthreads();
+        const int g = sh_g;
+        __syncthreads();
+        if (g < 0) break;
         const Pool a = pool_at(p, p.cj_from[g]), b = pool_at(p, p.which[g] & POOL_MASK);
         if (tid == 0) b.nd[0] = a.nd[p.cj_root[g]]; // C0 is still an OLD index until scanned
         __threadfence_block();
@@ -519,6 +537,7 @@ __device__ void compact_jobs(const Params &p, const int wg, const int n_wg) {
         }
         if (tid == 0) {
             p.alloc[g] = f;
+            p.cjob_list[job] = -1;                             // (empty again for the next launch)
             atomicExch(&p.spare[p.cj_entry[g]], p.cj_from[g]); // the old pool changes hands
             if (f + p.need_per_move > p.cap) atomicOr(p.faults, AZ_FAULT_POOL_EXHAUSTED);
         }
@@ -526,8 +545,9 @@ __device__ void compact_jobs(const Params &p, const int wg, const int n_wg) {
     }
     if (tid == 0) {
         __threadfence();
-        if (atomicAdd(p.cjob_count + 2, 1) == n_wg - 1) { // every extra workgroup has read n_jobs and finished its jobs
-            p.cjob_count[par] = 0;
+        if (atomicAdd(p.cjob_count + 2, 1) == n_wg - 1) { // every extra workgroup has seen all slot waves counted out and is done
+            p.cjob_count[0] = 0;
+            p.cjob_count[1] = 0;
             p.cjob_count[2] = 0;
         }
     }
@@ -605,7 +625,7 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         rsv_np = __shfl(rsv_np, 0);
         if (rsv_np < 0) return;
     }
-    bool queued = false; // the re-rooting of this move queued a compaction: the slot resumes after the next tick
+    bool queued = false; // the re-rooting of this move needs a compaction: the job is published below, after the slot's state
     auto release_rsv = [&]() { // (paths that leave the move step early hand an unused reservation back)
         if (rsv_np >= 0 && lane == 0) atomicExch(&p.spare[rsv_k], rsv_np);
         rsv_np = -1;
@@ -805,13 +825,17 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
     fault = wave_or(fault);
     if (lane == 0) {
         if (rsv_np >= 0) atomicExch(&p.spare[rsv_k], rsv_np); // reserved, not needed after all (game over, fresh tree, leaf root)
-        if (queued && !fault) p.cj_phase[g] = ph;
-        slot_store(p, g, sr, fault ? PH_IDLE : (queued ? PH_COMPACTING : ph));
+        slot_store(p, g, sr, fault ? PH_IDLE : ph);
         unsigned long long *st = p.stats + (size_t)g * ST_N;
         st[ST_MOVES] += st_moves;
         st[ST_EVALS] += st_evals;
         st[ST_COMPACT] += st_compact;
         if (fault) atomicOr(p.faults, fault);
+        if (queued) { // hand the copy to this launch's extra workgroups: everything they read (cj_*, which[g]) and the alloc
+                      // placeholder they overwrite is stored above; the release makes it visible before the slot index is
+            const int j = atomicAdd(p.cjob_count + 0, 1);
+            __hip_atomic_store(p.cjob_list + j, g, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -821,14 +845,9 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
 // MAPPED = true (az_engine_advance_rows, the thinned-out tail of a generation): it covers the first g_end entries of the
 // dense list row_slot[]; entry i writes its request to row i, and reads the answer to its previous request from row req_row[g].
 template <int GAME, int NP, bool MAPPED>
-__global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_first, const int g_end, const float *__restrict__ priors,
-                                                         const float *__restrict__ values, float *__restrict__ obs_out) {
+__device__ __forceinline__ void advance_slot_wave(const Params &p, const int g_first, const int g_end, const float *__restrict__ priors,
+                                                  const float *__restrict__ values, float *__restrict__ obs_out) {
     const int lane = threadIdx.x & 63;
-    const int n_slot_wgs = (g_end - g_first + 3) >> 2;
-    if ((int)blockIdx.x >= n_slot_wgs) { // (only launched when p.defer_compact) the jobs the launch before queued
-        compact_jobs(p, (int)blockIdx.x - n_slot_wgs, (int)gridDim.x - n_slot_wgs);
-        return;
-    }
     const int row = g_first + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= g_end) return;
     const int g = MAPPED ? rfl(p.row_slot[row]) : row;
@@ -852,10 +871,6 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
                                                                     // root request: ends this slot's tick
         if (MAPPED && lane == 0) p.req_row[g] = row;
         move_step<GAME>(p, g, lane, ph, sr, obs_row);
-        return;
-    }
-    if (ph == PH_COMPACTING) { // this launch's extra workgroups are copying the slot's tree: resume next tick (alloc[g] is theirs)
-        if (lane == 0) p.phase[g] = p.cj_phase[g];
         return;
     }
     if (ph != PH_RUN && ph != PH_WAIT_LEAF && ph != PH_WAIT_ROOT) return;
@@ -1115,6 +1130,22 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
     }
 }
 
+template <int GAME, int NP, bool MAPPED>
+__global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_first, const int g_end, const float *__restrict__ priors,
+                                                         const float *__restrict__ values, float *__restrict__ obs_out) {
+    const int n_slot_wgs = (g_end - g_first + 3) >> 2;
+    if ((int)blockIdx.x >= n_slot_wgs) { // (only launched when p.defer_compact) the copies this launch's slot waves hand over
+        compact_jobs(p, (int)blockIdx.x - n_slot_wgs, (int)gridDim.x - n_slot_wgs, n_slot_wgs * 4);
+        return;
+    }
+    advance_slot_wave<GAME, NP, MAPPED>(p, g_first, g_end, priors, values, obs_out);
+    // every slot wave counts itself out, whichever way it left: the extra workgroups stay until nobody can publish a job any more
+    if (p.defer_compact && (threadIdx.x & 63) == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(p.cjob_count + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Arena opponents (evaluation games, game_utils.py:16-145): ONE THREAD per slot whose opponent is to move.
 //  * AZ_OPPONENT_RANDOM - pyspiel.make_uniform_random_bot: a uniformly random legal action.
@@ -1343,6 +1374,7 @@ __global__ void az_reset_kernel(Params p) {
                       : (p.start.ply >= (p.arena_agent == AZ_ARENA_SELF_PLAY ? 1 : 2) ? p.select_rule : AZ_SELECT_PUCT)) << 30; // pool g, start_rule
     for (int k = g; k < p.n_spare; k += p.G) p.spare[k] = p.G + k; // the spare pools follow the slots' own
     if (g == 0) p.cjob_count[0] = p.cjob_count[1] = p.cjob_count[2] = 0;
+    p.cjob_list[g] = -1;
     p.root[g] = 0;
     p.alloc[g] = 1;
     p.depth[g] = 0;
@@ -1566,7 +1598,7 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
 #define DA(ptr, n) if (rc == AZ_OK) rc = dalloc(e, &(ptr), (n))
     DA(p.nodes, nodes);
     DA(p.spare, (size_t)p.n_spare);
-    DA(p.cjob_list, 2 * G); DA(p.cjob_count, 3); DA(p.cj_from, G); DA(p.cj_entry, G); DA(p.cj_phase, G); DA(p.cj_root, G);
+    DA(p.cjob_list, G); DA(p.cjob_count, 3); DA(p.cj_from, G); DA(p.cj_entry, G); DA(p.cj_root, G);
     DA(p.row_slot, G); DA(p.req_row, G); DA(p.n_rows_live, 1);
     DA(p.phase, G); DA(p.gid, G); DA(p.ply, G); DA(p.sims, G); DA(p.which, G); DA(p.depth, G); DA(p.leaf_ply, G);
     DA(p.root, G); DA(p.alloc, G); DA(p.leaf_node, G); DA(p.path, G * p.pstride);
@@ -1634,7 +1666,6 @@ extern "C" int az_engine_reset(az_engine *e, uint64_t seed, int64_t n_games, voi
     HIPCHK(e, hipGetLastError());
     e->reset_done = true;
     e->ticks = 0;
-    e->cj_parity = 0;
     e->rows_mapped = false;
     e->rows_live = 0;
     return AZ_OK;
@@ -1702,8 +1733,8 @@ extern "C" int az_engine_set_start_prefix(az_engine *e, const int32_t *actions, 
     return AZ_OK;
 }
 
-// `defer`: compactions of this launch are queued for the extra workgroups of the NEXT such launch (compact_jobs; whole-engine
-// launches only: the job lists are one pair per engine, and slot groups ticking on their own streams would share them).
+// `defer`: compactions of this launch are handed to its own extra workgroups (compact_jobs; whole-engine launches only: the job
+// list and its counters are one set per engine, and slot groups ticking on their own streams would share them).
 template <bool MAPPED>
 static int advance_range(az_engine *e, int g_first, int g_end, const float *priors, const float *values, float *obs_out, void *stream,
                          bool defer) {
@@ -1712,8 +1743,6 @@ static int advance_range(az_engine *e, int g_first, int g_end, const float *prio
     defer = defer && e->may_compact;
     dim3 grid((g_end - g_first + 3) / 4 + (defer ? AZ_COMPACT_WGS : 0)), block(256);
     e->p.defer_compact = defer ? 1 : 0;
-    e->p.cj_parity = e->cj_parity;
-    if (defer) e->cj_parity ^= 1;
     if (e->cfg.game == AZ_GAME_CONNECT_FOUR) {
         hipLaunchKernelGGL((az_advance_kernel<AZG_CONNECT_FOUR, 1, MAPPED>), grid, block, 0, st, e->p, g_first, g_end, priors, values, obs_out);
     } else {

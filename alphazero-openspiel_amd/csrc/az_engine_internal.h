@@ -12,8 +12,7 @@
 #define NONE32 0xFFFFFFFFu
 
 enum { PH_IDLE = 0, PH_RUN = 1, PH_MOVE = 2, PH_WAIT_ROOT = 3, PH_WAIT_LEAF = 4, PH_SEARCH_DONE = 5, PH_NEED_ROOT = 6,
-       PH_OPPONENT = 7 /* arena: the opponent bot is to move */, PH_OPP_DONE = 8 /* ... and has chosen (opp_action) */,
-       PH_COMPACTING = 9 /* its subtree is being copied into a new pool by this launch's extra workgroups: sits the tick out */ };
+       PH_OPPONENT = 7 /* arena: the opponent bot is to move */, PH_OPP_DONE = 8 /* ... and has chosen (opp_action) */ };
 enum { ST_MOVES = 0, ST_SIMS, ST_EVALS, ST_TERM, ST_DEPTH, ST_CHILDREN, ST_NODES, ST_COMPACT, ST_N };
 
 // One search-tree node (mcts.py:10-20 Node: N, Q, P, children).  32 bytes, so a block of sibling nodes is one
@@ -50,12 +49,14 @@ struct Params {
     AzNode *nodes;
     int n_spare;
     int *spare;
-    // deferred compaction: a slot that must compact while re-rooting takes a spare pool, becomes its owner (root 0), queues a
-    // job and sits the NEXT tick out (PH_COMPACTING) while that tick's extra workgroups copy the subtree, a workgroup per job.
-    int defer_compact;              // this launch may queue jobs and carries the extra workgroups (set per launch by the host)
-    int cj_parity;                  // jobs queued by this launch go to list cj_parity; its extra workgroups work off list 1 - cj_parity
-    int *cjob_list, *cjob_count;    // [2][G] queued slots; cjob_count[0..1] = their numbers, [2] = extra workgroups done
-    int *cj_from, *cj_entry, *cj_phase; // [G] the pool the subtree is copied out of; the spare[] entry that takes it back; the phase to resume in
+    // handed-over compaction: a slot that must compact while re-rooting takes a spare pool, becomes its owner (root 0) and
+    // publishes a job once its own state is stored; the extra workgroups of the SAME launch copy the subtree, a workgroup per
+    // job, and leave only when every slot wave of the launch has finished and the list is drained.  Nothing about a job outlives
+    // its launch (no host-side parity or epoch: a captured graph replays any number of launches).
+    int defer_compact;              // this launch carries the extra workgroups (set per launch by the host)
+    int *cjob_list, *cjob_count;    // [G] published slots (-1 = empty); cjob_count[0] = positions taken, [1] = slot waves finished,
+                                    // [2] = extra workgroups finished (the last one clears all three)
+    int *cj_from, *cj_entry;        // [G] the pool the subtree is copied out of; the spare[] entry that takes it back
     uint32_t *cj_root;              // [G] index of the new root in that pool
     // per slot
     int *phase, *gid, *ply, *sims, *which, *depth, *leaf_ply;
@@ -108,7 +109,6 @@ struct az_engine {
     bool rows_mapped = false; // az_engine_compact_rows has been called since the last reset
     int rows_live = 0;
     bool may_compact = false; // a pool cannot hold a whole game: re-rooting may have to compact (launches carry extra workgroups)
-    int cj_parity = 0;        // job list the next deferred launch queues into
     // host mirrors for export
     std::vector<int32_t> h_len;
     std::vector<float> h_ret0;

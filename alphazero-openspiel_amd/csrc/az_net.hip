@@ -45,7 +45,9 @@ struct az_net {
     int max_boards = 0;
     int bpw_max = 0, lds_head = 0, n_ot = 0, r3 = 16;
     int precision = AZ_NET_PREC_F16;
-    bool x3b = false; // f16x3 on a row-pair board with <= 50 filters: az_tower_x3b_kernel (no output-channel tile for channels 48, 49)
+    bool x3b = false; // f16x3 on a row-pair board with <= 50 filters: the x3b scheme (no output-channel tile for channels 48, 49)
+    bool x3p = true;  // ... full batches on az_tower_x3p_kernel (two waves per board); AZ_NET_TOWER=x3b in the environment at
+                      // az_net_create keeps az_tower_x3b_kernel (one wave per board) for same-box A/B runs - same bits either way
 };
 static std::string g_net_err;
 
@@ -263,6 +265,8 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     if (n->precision == AZ_NET_PREC_F16X3) {
         X3Geom g = x3_geom(d.rows, d.cols, d.n_filters <= 50 ? 2 : 16);
         n->x3b = g.rp1 && d.n_filters <= 50; // row-pair board, channels 48, 49 the only ones past three tiles
+        const char *tw = getenv("AZ_NET_TOWER");
+        n->x3p = !(tw && strcmp(tw, "x3b") == 0);
         if (!n->x3b && (g.nt > 4 || g.lds > 160 * 1024)) {
             g_net_err = "board / filter count does not fit the f16x3 tower kernel's LDS budget";
             delete n;
@@ -547,7 +551,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         tp.A = n->d.num_actions;
         tp.fc_ksteps = hp.ksteps;
         hipError_t s = x3c ? az_launch_tower_x3c(n->d.device, n_boards > AZ_X3C_ONE_PER_WG ? 2 : 1, tp, n_boards, st)
-                       : n->x3b ? az_launch_tower_x3b(n->d.device, tp, grid, st)
+                       : n->x3b ? (n->x3p ? az_launch_tower_x3p(n->d.device, tp, grid, st) : az_launch_tower_x3b(n->d.device, tp, grid, st))
                               : az_launch_tower_x3(n->d.device, g.nt, g.rp1, n->r3, tp, grid, g.lds, st);
         if (s != hipSuccess) {
             n->err = std::string("f16x3 tower launch: ") + hipGetErrorString(s);

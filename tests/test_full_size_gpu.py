@@ -25,12 +25,12 @@ pytestmark = pytest.mark.gpu
 S, G, N_GAMES = 400, 4096, 4096
 
 
-def _play(n_slots, n_games, seed, keep_engine=False, **engine_kw):
+def _play(n_slots, n_games, seed, keep_engine=False, precision="f16", **engine_kw):
     from alphazero_openspiel_amd import engine as E, fusednet
     from alphazero_openspiel_amd.network import Net
     torch.manual_seed(0)
     net = Net([3, 6, 7], 7, n_blocks=10, n_filters=50).eval()
-    fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots, precision="f16")
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_slots, precision=precision)
     eng = E.SelfPlayEngine("connect_four", n_slots, n_playouts=S, max_games=n_games, seed=seed, device=0, **engine_kw)
     prog = E.run_selfplay(eng, fn, n_games, use_graph=True)
     assert prog["games_done"] == n_games and prog["error_flags"] == 0
@@ -42,16 +42,18 @@ def _play(n_slots, n_games, seed, keep_engine=False, **engine_kw):
     return ex, prog
 
 
-@pytest.fixture(scope="module")
-def full_run():
-    ex, prog, eng, fn = _play(G, N_GAMES, seed=2024, keep_engine=True)
-    yield ex, prog, eng
+# both evaluator precisions: "f32x" is the product default and what bench.py times (fp32-grade, the reference's Net.forward
+# precision: network.py:48-64 runs in fp32), "f16" the opt-in
+@pytest.fixture(scope="module", params=["f32x", "f16"])
+def full_run(request):
+    ex, prog, eng, fn = _play(G, N_GAMES, seed=2024, keep_engine=True, precision=request.param)
+    yield ex, prog, eng, request.param
     eng.close()
     fn.close()
 
 
 def test_full_size_games_obey_the_rules_and_conserve_visits(full_run):
-    ex, prog, _ = full_run
+    ex, prog, _, _ = full_run
     game = games.load_game("connect_four")
     n_first_searches = 0
     for g in range(N_GAMES):
@@ -85,8 +87,8 @@ def test_full_size_games_obey_the_rules_and_conserve_visits(full_run):
 
 
 def test_records_do_not_depend_on_the_number_of_slots(full_run):
-    ex, _, _ = full_run
-    ex_small, prog_small = _play(1024, N_GAMES, seed=2024)
+    ex, _, _, precision = full_run
+    ex_small, prog_small = _play(1024, N_GAMES, seed=2024, precision=precision)
     assert prog_small["ticks"] > 0
     for k in ("game_len", "game_ret0"):
         assert (ex[k] == ex_small[k]).all(), k
@@ -104,9 +106,9 @@ def test_records_do_not_depend_on_the_number_of_slots(full_run):
 def test_records_do_not_depend_on_tick_scheduling(full_run):
     """How many NN-free playouts a slot chains per tick (count cap, time window) is scheduling only: one playout per
     tick with the window off gives the same games as the defaults, bit for bit (first 512 games compared)."""
-    ex, _, _ = full_run
+    ex, _, _, precision = full_run
     n = 512
-    ex_b, prog_b = _play(512, n, seed=2024, max_sims_per_tick=1, chain_window_us=-1)
+    ex_b, prog_b = _play(512, n, seed=2024, precision=precision, max_sims_per_tick=1, chain_window_us=-1)
     assert (ex["game_len"][:n] == ex_b["game_len"]).all() and (ex["game_ret0"][:n] == ex_b["game_ret0"]).all()
     live_ply = np.arange(ex_b["move"].shape[1])[None, :] < ex_b["game_len"][:, None]
     live_child = live_ply[:, :, None] & (np.arange(ex_b["child_visits"].shape[2])[None, None, :]
@@ -120,7 +122,9 @@ def test_records_do_not_depend_on_tick_scheduling(full_run):
 def test_replay_store_at_full_size(full_run):
     from alphazero_openspiel_amd import replay
     from alphazero_openspiel_amd.engine import pi_from_visits
-    ex, _, eng = full_run
+    ex, _, eng, precision = full_run
+    if precision != "f32x":
+        pytest.skip("the replay store is independent of the evaluator; run once, on the product-default generation")
     rep = replay.DeviceReplay("connect_four", max_games=N_GAMES, device=0)
     rep.set_capacity(N_GAMES)
     rep.append_engine(eng)

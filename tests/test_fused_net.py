@@ -102,6 +102,34 @@ def test_net_matches_reference_golden_outputs():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f32x", "f16"])
+@pytest.mark.parametrize("tag,shape,A", [("connect_four", [3, 6, 7], 7), ("breakthrough6", [3, 6, 6], 432)])
+def test_fused_forward_matches_the_reference_held_outputs(tag, shape, A, precision):
+    """The HIP towers against the outputs the REFERENCE's own Net.forward (network.py:48-64) produced for its shipped checkpoints
+    (tests/golden/net_forward_*.npz, written by oracle/gen_golden.py running the real reference): no torch module in between.
+    f32x (the product default): 2e-5, the grade the fixture itself is pinned to on CPU; f16 (opt-in): P_TOL / V_TOL."""
+    net = load_npz_checkpoint(os.path.join(GOLDEN, "checkpoint_%s.npz" % tag), shape, A).eval()
+    z = np.load(os.path.join(GOLDEN, "net_forward_%s.npz" % tag))
+    boards = z["boards"].astype(np.float32)
+    n = boards.shape[0]
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=max(n, 16), precision=precision)
+    pf, vf = fn.forward(torch.from_numpy(boards).cuda())
+    torch.cuda.synchronize()
+    pf, vf = pf.cpu().numpy(), vf.cpu().numpy()
+    fn.close()
+    dp, dv = np.abs(pf - z["p"]).max(), np.abs(vf - z["v"].reshape(-1)).max()
+    p_tol, v_tol = (2e-5, 2e-5) if precision == "f32x" else (P_TOL, V_TOL)
+    assert dp <= p_tol and dv <= v_tol, (dp, dv)
+    # the same boards inside a batch large enough for the full-batch kernels (x3b / az_tower_kernel): same bits as above
+    big = np.concatenate([boards] * (600 // n + 1))[:600]
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=600, precision=precision)
+    pb, vb = fn.forward(torch.from_numpy(big).cuda())
+    torch.cuda.synchronize()
+    assert (pb.cpu().numpy()[:n] == pf).all() and (vb.cpu().numpy()[:n] == vf).all()
+    fn.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag,n", [("c4_ckpt", 24), ("c4_ckpt", 1), ("c4_ckpt", 157), ("bt6_ckpt", 40),
                                    ("c4_10block", 300), ("bt8_2block", 37), ("bt5x4_3block", 50),
                                    ("bt4x5_2block", 3), ("bt4x5_2block", 130), ("c4_10block", 4096),
