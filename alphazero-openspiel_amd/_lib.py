@@ -115,7 +115,7 @@ PROTOTYPES = [
     ("az_net_reserve", C.c_int, [_vp, C.c_int32]),
     ("az_net_read_tower", C.c_int, [_vp, C.POINTER(C.c_float), C.c_int32]),
     ("az_net_issued_mfma_per_board", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_double)]),
-    ("az_net_kernel_label", C.c_char_p, [_vp]),
+    ("az_net_kernel_label", C.c_char_p, [_vp, C.c_int32]),
     ("az_replay_create", C.c_int, [C.POINTER(AzReplayConfig), C.POINTER(_vp)]),
     ("az_replay_destroy", C.c_int, [_vp]),
     ("az_replay_last_error", C.c_char_p, [_vp]),

@@ -452,42 +452,55 @@ __device__ void reroot(const Params &p, int g, SlotRegs &sr, Pool &t, int sel, b
     }
 }
 
-// Handed-over compaction: the last AZ_COMPACT_WGS workgroups of a tick kernel launch take the jobs the slot waves of the SAME launch
-// publish (move_step: the slot's state is stored, then its index goes into cjob_list with release semantics), beside the other slots'
+// Handed-over compaction: the last AZ_COMPACT_WGS workgroups of a tick kernel launch take the copies the slot waves of the SAME launch
+// hand over (move_step: the slot's state is stored, then cj_job[row] = slot + 1 with release semantics), beside the other slots'
 // playouts.  One 256-thread workgroup per job copies the subtree under cj_root[g] of pool cj_from[g] into the slot's new pool,
 // breadth first, 256 parents per round: the children of a round are numbered by a block-wide prefix sum (the SAME order - hence
 // the same node indices - as compact_subtree's wave-wide one) and copied one node per thread and step, so a round is two or three
-// memory round trips whatever the fan-out.  Workgroup w takes positions w, w + n_wg, ... of the list; an empty position is polled
-// until it fills or every slot wave of the launch has counted itself out (cjob_count[1] == n_slot_waves: nobody can publish any
-// more), so the launch ends with every job done and a slot never carries a pending copy across launches - a captured graph may
-// hold any number of launches, and the other entry points (advance_slots, read_tree, ...) never meet a half-copied pool.  The last
-// workgroup out clears the counters.  (The copies ran in a kernel of their own for a day: 4.9 us per tick, empty or not; then in
-// the NEXT launch, keyed by a host-side parity that a graph of an odd number of launches froze: ADVICE r3.)
+// memory round trips whatever the fan-out.
+// Who serves whom, and when a workgroup may leave: extra workgroup k owns rows [k R, (k + 1) R) of the launch (R = rows / workgroups,
+// rounded up).  Every slot wave ends by storing the launch's epoch into cj_seen[row] (a plain agent-scope store to an address of
+// its own - a shared counter of finished waves, 2048 atomic adds on one address per launch, added 20 us to every launch); the
+// workgroup polls its rows' cj_job and cj_seen (one or two coalesced loads a microsecond) and leaves when all of them have been
+// seen and none has a job - so the launch ends with every job done, and a slot never carries a pending copy across launches: a
+// captured graph may hold any number of launches, and the other entry points (advance_slots, read_tree, ...) never meet a
+// half-copied pool.  The epoch is a device counter the last extra workgroup out advances: constant while a launch runs (nothing
+// host-side that a graph would freeze).  (The copies ran in a kernel of their own for a day: 4.9 us per tick, empty or not; then
+// in the NEXT launch, keyed by a host-side parity that a graph of an odd number of launches froze: ADVICE r3.)
 #define CJ_THREADS 256
 #define AZ_COMPACT_WGS 64 // extra workgroups per launch (jobs are rare; a burst is worked off 64 at a time)
-__device__ void compact_jobs(const Params &p, const int wg, const int n_wg, const int n_slot_waves) {
+__device__ void compact_jobs(const Params &p, const int wg, const int n_wg, const int n_rows) {
     __shared__ uint32_t sh_off[CJ_THREADS + 1], sh_c0[CJ_THREADS];
     __shared__ int sh_wave[CJ_THREADS / 64];
-    __shared__ int sh_g;
+    __shared__ int sh_job, sh_unseen;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int job = wg; job < p.G; job += n_wg) {
-        if (tid == 0) {
-            int g = -1;
-            bool over = false;
-            for (int spin = 0; spin < (1 << 22); spin++) { // (bounded: ~a second; a launch lasts tens of microseconds)
-                g = __hip_atomic_load(p.cjob_list + job, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                if (g >= 0 || over) break;
-                // every publish precedes its wave's count: once all waves are counted, one more look at the position settles it
-                over = __hip_atomic_load(p.cjob_count + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= n_slot_waves;
-                if (!over) __builtin_amdgcn_s_sleep(16);
-            }
-            if (g < 0 && !over) atomicOr(p.faults, AZ_FAULT_POOL_EXHAUSTED); // (the slot waves never finished: wedged device)
-            sh_g = g;
+    const int epoch = p.cjob_count[0];
+    const int per = (n_rows + n_wg - 1) / n_wg, r0 = wg * per, r1 = r0 + per < n_rows ? r0 + per : n_rows;
+    bool confirmed = false;
+    for (int spin = 0; r0 < r1 && spin < (1 << 20); spin++) { // (bounded: ~a second; a launch lasts tens of microseconds)
+        if (tid == 0) sh_job = -1, sh_unseen = 0;
+        __syncthreads();
+        for (int r = r0 + tid; r < r1; r += CJ_THREADS) { // relaxed polls (an acquire per poll would invalidate this XCD's L2 under the slot waves)
+            // (seen first: a wave's job store is acknowledged before its seen store is issued, so "seen and no job" is final)
+            const int seen = __hip_atomic_load(p.cj_seen + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int j = __hip_atomic_load(p.cj_job + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (j > 0) sh_job = r; // (any one of them: benign race)
+            if (seen != epoch) sh_unseen = 1;
         }
         __syncthreads();
-        const int g = sh_g;
+        const int jr = sh_job, unseen = sh_unseen;
         __syncthreads();
-        if (g < 0) break;
+        if (jr < 0) {
+            if (!unseen) {
+                if (confirmed) break; // (the pass before saw every row out; THIS pass's job loads were issued after those had returned)
+                confirmed = true;
+                continue;
+            }
+            __builtin_amdgcn_s_sleep(48);
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // ONE acquire per job: what the publisher stored before its release
+        const int g = __hip_atomic_load(p.cj_job + jr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
         const Pool a = pool_at(p, p.cj_from[g]), b = pool_at(p, p.which[g] & POOL_MASK);
         if (tid == 0) b.nd[0] = a.nd[p.cj_root[g]]; // C0 is still an OLD index until scanned
         __threadfence_block();
@@ -537,18 +550,17 @@ __device__ void compact_jobs(const Params &p, const int wg, const int n_wg, cons
         }
         if (tid == 0) {
             p.alloc[g] = f;
-            p.cjob_list[job] = -1;                             // (empty again for the next launch)
-            atomicExch(&p.spare[p.cj_entry[g]], p.cj_from[g]); // the old pool changes hands
+            __hip_atomic_store(p.cj_job + jr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (done; its own next poll must see it)
+            atomicExch(&p.spare[p.cj_entry[g]], p.cj_from[g]);                               // the old pool changes hands
             if (f + p.need_per_move > p.cap) atomicOr(p.faults, AZ_FAULT_POOL_EXHAUSTED);
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(p.cjob_count + 2, 1) == n_wg - 1) { // every extra workgroup has seen all slot waves counted out and is done
-            p.cjob_count[0] = 0;
-            p.cjob_count[1] = 0;
+    if (tid == 0) { // (no fence: nothing here is read before the launch ends, and an agent-scope release at this point - the XCD's L2
+                    //  full of the launch's node writes - is tens of microseconds)
+        if (atomicAdd(p.cjob_count + 2, 1) == n_wg - 1) { // every extra workgroup has seen its rows out and is done: the next launch's epoch
             p.cjob_count[2] = 0;
+            p.cjob_count[0] = epoch + 1;
         }
     }
 }
@@ -599,7 +611,7 @@ __device__ __forceinline__ bool opponent_to_move(const Params &p, int gid, const
 // per tick; now moving slots run beside the other slots' playouts).
 template <int GAME>
 __device__ __forceinline__ void move_step(const Params &p, const int g, const int lane, int ph, SlotRegs sr,
-                                          float *__restrict__ obs_row) { // obs_row: this slot's row of the request buffer
+                                          float *__restrict__ obs_row, const int row) { // obs_row: row `row` of the request buffer, this slot's
     const AzGeom &geom = p.geom;
     Pool t = pool_at(p, sr.pool);
     unsigned long long st_moves = 0, st_evals = 0, st_compact = 0;
@@ -832,9 +844,10 @@ __device__ __forceinline__ void move_step(const Params &p, const int g, const in
         st[ST_COMPACT] += st_compact;
         if (fault) atomicOr(p.faults, fault);
         if (queued) { // hand the copy to this launch's extra workgroups: everything they read (cj_*, which[g]) and the alloc
-                      // placeholder they overwrite is stored above; the release makes it visible before the slot index is
-            const int j = atomicAdd(p.cjob_count + 0, 1);
-            __hip_atomic_store(p.cjob_list + j, g, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                      // placeholder they overwrite is stored above; the release makes it visible before the job is, and the job
+                      // is acknowledged before this wave reports itself seen (az_advance_kernel)
+            __hip_atomic_store(p.cj_job + row, g + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
 }
@@ -870,7 +883,7 @@ __device__ __forceinline__ void advance_slot_wave(const Params &p, const int g_f
     if (ph == PH_MOVE || ph == PH_NEED_ROOT || ph == PH_OPP_DONE) { // the agent's move / the opponent's move / the next search's
                                                                     // root request: ends this slot's tick
         if (MAPPED && lane == 0) p.req_row[g] = row;
-        move_step<GAME>(p, g, lane, ph, sr, obs_row);
+        move_step<GAME>(p, g, lane, ph, sr, obs_row, row);
         return;
     }
     if (ph != PH_RUN && ph != PH_WAIT_LEAF && ph != PH_WAIT_ROOT) return;
@@ -1135,15 +1148,15 @@ __global__ __launch_bounds__(256) void az_advance_kernel(Params p, const int g_f
                                                          const float *__restrict__ values, float *__restrict__ obs_out) {
     const int n_slot_wgs = (g_end - g_first + 3) >> 2;
     if ((int)blockIdx.x >= n_slot_wgs) { // (only launched when p.defer_compact) the copies this launch's slot waves hand over
-        compact_jobs(p, (int)blockIdx.x - n_slot_wgs, (int)gridDim.x - n_slot_wgs, n_slot_wgs * 4);
+        compact_jobs(p, (int)blockIdx.x - n_slot_wgs, (int)gridDim.x - n_slot_wgs, g_end - g_first);
         return;
     }
+    const int epoch = p.defer_compact ? p.cjob_count[0] : 0; // (the same in every wave of the launch: compact_jobs)
     advance_slot_wave<GAME, NP, MAPPED>(p, g_first, g_end, priors, values, obs_out);
-    // every slot wave counts itself out, whichever way it left: the extra workgroups stay until nobody can publish a job any more
-    if (p.defer_compact && (threadIdx.x & 63) == 0) {
-        __threadfence();
-        __hip_atomic_fetch_add(p.cjob_count + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // every slot wave reports itself seen, whichever way it left: its extra workgroup stays until none of its rows can hand over a job
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p.defer_compact && (threadIdx.x & 63) == 0 && g_first + row < g_end)
+        __hip_atomic_store(p.cj_seen + row, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1373,8 +1386,9 @@ __global__ void az_reset_kernel(Params p) {
     p.which[g] = g | (!p.keep_tree || p.manual_moves ? AZ_SELECT_PUCT
                       : (p.start.ply >= (p.arena_agent == AZ_ARENA_SELF_PLAY ? 1 : 2) ? p.select_rule : AZ_SELECT_PUCT)) << 30; // pool g, start_rule
     for (int k = g; k < p.n_spare; k += p.G) p.spare[k] = p.G + k; // the spare pools follow the slots' own
-    if (g == 0) p.cjob_count[0] = p.cjob_count[1] = p.cjob_count[2] = 0;
-    p.cjob_list[g] = -1;
+    if (g == 0) p.cjob_count[0] = 1, p.cjob_count[1] = p.cjob_count[2] = 0; // epoch 1: no row has been seen in it
+    p.cj_job[g] = 0;
+    p.cj_seen[g] = 0;
     p.root[g] = 0;
     p.alloc[g] = 1;
     p.depth[g] = 0;
@@ -1598,7 +1612,7 @@ extern "C" int az_engine_create(const az_config *cfg, az_engine **out) {
 #define DA(ptr, n) if (rc == AZ_OK) rc = dalloc(e, &(ptr), (n))
     DA(p.nodes, nodes);
     DA(p.spare, (size_t)p.n_spare);
-    DA(p.cjob_list, G); DA(p.cjob_count, 3); DA(p.cj_from, G); DA(p.cj_entry, G); DA(p.cj_root, G);
+    DA(p.cj_job, G); DA(p.cj_seen, G); DA(p.cjob_count, 3); DA(p.cj_from, G); DA(p.cj_entry, G); DA(p.cj_root, G);
     DA(p.row_slot, G); DA(p.req_row, G); DA(p.n_rows_live, 1);
     DA(p.phase, G); DA(p.gid, G); DA(p.ply, G); DA(p.sims, G); DA(p.which, G); DA(p.depth, G); DA(p.leaf_ply, G);
     DA(p.root, G); DA(p.alloc, G); DA(p.leaf_node, G); DA(p.path, G * p.pstride);

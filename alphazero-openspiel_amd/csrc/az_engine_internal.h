@@ -54,8 +54,10 @@ struct Params {
     // job, and leave only when every slot wave of the launch has finished and the list is drained.  Nothing about a job outlives
     // its launch (no host-side parity or epoch: a captured graph replays any number of launches).
     int defer_compact;              // this launch carries the extra workgroups (set per launch by the host)
-    int *cjob_list, *cjob_count;    // [G] published slots (-1 = empty); cjob_count[0] = positions taken, [1] = slot waves finished,
-                                    // [2] = extra workgroups finished (the last one clears all three)
+    int *cj_job, *cj_seen;          // [G] by ROW of the launch: slot + 1 whose copy the row's wave handed over (0: none); the epoch in
+                                    // which the row's wave last finished
+    int *cjob_count;                // [0] = the epoch of the running launch (advanced by the last extra workgroup out), [2] = extra
+                                    // workgroups finished
     int *cj_from, *cj_entry;        // [G] the pool the subtree is copied out of; the spare[] entry that takes it back
     uint32_t *cj_root;              // [G] index of the new root in that pool
     // per slot

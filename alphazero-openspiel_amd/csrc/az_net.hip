@@ -46,8 +46,13 @@ struct az_net {
     int bpw_max = 0, lds_head = 0, n_ot = 0, r3 = 16;
     int precision = AZ_NET_PREC_F16;
     bool x3b = false; // f16x3 on a row-pair board with <= 50 filters: the x3b scheme (no output-channel tile for channels 48, 49)
-    bool x3p = true;  // ... full batches on az_tower_x3p_kernel (two waves per board); AZ_NET_TOWER=x3b in the environment at
-                      // az_net_create keeps az_tower_x3b_kernel (one wave per board) for same-box A/B runs - same bits either way
+    // f16x3 with <= 50 filters on a board whose positions pack into whole column tiles (6x7, 6x6, 8x8): az_tower_x3d_kernel.
+    // AZ_NET_TOWER=x3b in the environment at az_net_create keeps the kernels of round 3 (az_tower_x3b_kernel / az_tower_x3_kernel)
+    // for same-box A/B runs; on row-pair boards the bits are the same either way.
+    int x3d = -1;                 // variant of az_launch_tower_x3d, -1: none
+    int xd_nb = 0, xd_R = 0, xd_rs = 0;
+    _Float16 *conv_w_d = nullptr; // the x3d weight stream (conv_w keeps the stream of the small-batch / fallback kernel)
+    uint16_t *xd_pos = nullptr, *xd_sdst = nullptr;
 };
 static std::string g_net_err;
 
@@ -74,6 +79,9 @@ extern "C" int az_net_destroy(az_net *n) {
     (void)hipFree(n->fc_b);
     (void)hipFree(n->skip_w);
     (void)hipFree(n->logits);
+    (void)hipFree(n->conv_w_d);
+    (void)hipFree(n->xd_pos);
+    (void)hipFree(n->xd_sdst);
     delete n;
     return AZ_OK;
 }
@@ -151,13 +159,41 @@ static inline uint16_t abi_weight(const uint16_t *src, int c, int co, int tap, i
     return src[(size_t)c * AZ_NET_KSTEPS * 2048 + ((((size_t)oks * 4 + mt) * 64 + olane) * 8) + (ch & 7)];
 }
 
-// Device weight stream of az_tower_x3b_kernel (layout: struct X3B, az_net_common.h; meaning of tiles T and X: az_tower_x3b.h).
-//   conv 0:       4 k-steps x [hi mt 0..2][lo mt 0..2], then T of each k-step
-//   conv c >= 1:  part 0: k-steps 0..3 | part 1: k-steps 4..7, then T, Xhi, Xlo of k-step 6 and of k-step 7 |
-//                 part 2: k-steps 8..11 | part 3: k-steps 12..14, then T of the gather k-step
-static void build_x3b_stream(const uint16_t *hi, const uint16_t *lo, int n_convs, std::vector<unsigned char> &dev) {
-    // (+ two chunks of zero padding: the kernel's fetch of "chunk + 2" is unconditional)
-    dev.assign((size_t)X3B::C0_B + (size_t)(n_convs - 1) * X3B::CONV_B + 2 * X3B::CONV_B, 0);
+// Device weight streams of the kernels on the x3b scheme (meaning of tiles T and X: az_tower_x3b.h).  A conv is cut into parts
+// (= LDS chunks): the part's k-step records [hi mt 0..2][lo mt 0..2], then the extra fragments of its k-steps in k-step order -
+// conv 0: T of every k-step; conv c >= 1: T, Xhi, Xlo of k-steps 6 and 7, T of the gather k-step 14.
+//   az_tower_x3b_kernel / az_tower_x3c_kernel (struct X3B): conv 0 = one part; conv c >= 1 = k-steps [0,4) [4,8) [8,12) [12,15)
+//   az_tower_x3d_kernel (struct X3D):                        conv 0 = [0,2) [2,4); conv c >= 1 = [0,3) [3,6) [6,8) [8,11) [11,14) [14]
+struct X3Stream {
+    int n_parts0, ks0_0[2], ks1_0[2];
+    size_t off_0[2], c0_b;
+    int n_parts, ks0[6], ks1[6];
+    size_t off[6], conv_b;
+};
+static X3Stream x3b_stream_layout() {
+    X3Stream L = {};
+    L.n_parts0 = 1, L.ks0_0[0] = 0, L.ks1_0[0] = AZ_NET_K0STEPS, L.off_0[0] = 0, L.c0_b = X3B::C0_B;
+    L.n_parts = X3B::PARTS, L.conv_b = X3B::CONV_B;
+    for (int part = 0; part < X3B::PARTS; part++) {
+        L.ks0[part] = part * X3B::CK;
+        L.ks1[part] = L.ks0[part] + X3B::CK < X3B::NKS ? L.ks0[part] + X3B::CK : X3B::NKS;
+        L.off[part] = X3B::part_off(part);
+    }
+    return L;
+}
+static X3Stream x3d_stream_layout() {
+    X3Stream L = {};
+    L.n_parts0 = X3D::PARTS0, L.c0_b = X3D::C0_B;
+    for (int part = 0; part < X3D::PARTS0; part++) L.ks0_0[part] = 2 * part, L.ks1_0[part] = 2 * part + 2, L.off_0[part] = (size_t)part * X3D::C0_PART_B;
+    L.n_parts = X3D::PARTS, L.conv_b = X3D::CONV_B;
+    for (int part = 0; part < X3D::PARTS; part++)
+        L.ks0[part] = X3D::part_ks0(part), L.ks1[part] = X3D::part_ks0(part) + X3D::part_len(part), L.off[part] = X3D::part_off(part);
+    return L;
+}
+static void build_x3_stream(const X3Stream &L, const uint16_t *hi, const uint16_t *lo, int n_convs, std::vector<unsigned char> &dev) {
+    // (+ two convs of zero padding: the kernels' fetch of "chunk + 2" is unconditional)
+    dev.assign(L.c0_b + (size_t)(n_convs - 1) * L.conv_b + 2 * L.conv_b, 0);
+    constexpr int FR = X3B::FR, REC2 = X3B::REC2;
     // one fragment: 64 lanes x 8 fp16; f(q, l15, j) -> bits
     auto put_frag = [&](size_t off, auto f) {
         uint16_t *o = (uint16_t *)&dev[off];
@@ -181,7 +217,7 @@ static void build_x3b_stream(const uint16_t *hi, const uint16_t *lo, int n_convs
     auto put_record = [&](size_t off, int c, int ks) { // [hi mt 0..2][lo mt 0..2]
         for (int part = 0; part < 2; part++)
             for (int mt = 0; mt < 3; mt++)
-                put_frag(off + (size_t)(part * 3 + mt) * X3B::FR,
+                put_frag(off + (size_t)(part * 3 + mt) * FR,
                          [&](int q, int l, int j) { return main_val(part ? lo : hi, c, 16 * mt + l, ks, q, j); });
     };
     // tile T: rows 0..3 = hi 48, hi 49, lo 48, lo 49 of a shifted-B k-step (conv 0's k-steps, the gather k-step);
@@ -205,25 +241,79 @@ static void build_x3b_stream(const uint16_t *hi, const uint16_t *lo, int n_convs
             return gp < 30 ? abi_weight(src, c, 48 + (l & 1), X3B::tap_of_plane(l >> 1), 8 * (gp - 24) + j) : 0;
         });
     };
-    size_t off = 0;
-    for (int ks = 0; ks < AZ_NET_K0STEPS; ks++, off += X3B::REC2) put_record(off, 0, ks);
-    for (int ks = 0; ks < AZ_NET_K0STEPS; ks++, off += X3B::FR) put_t(off, 0, ks);
+    for (int part = 0; part < L.n_parts0; part++) {
+        size_t off = L.off_0[part];
+        for (int ks = L.ks0_0[part]; ks < L.ks1_0[part]; ks++, off += REC2) put_record(off, 0, ks);
+        for (int ks = L.ks0_0[part]; ks < L.ks1_0[part]; ks++, off += FR) put_t(off, 0, ks);
+    }
     for (int c = 1; c < n_convs; c++) {
-        const size_t base = (size_t)X3B::C0_B + (size_t)(c - 1) * X3B::CONV_B;
-        for (int part = 0; part < X3B::PARTS; part++) {
-            off = base + X3B::part_off(part);
-            const int ks0 = part * X3B::CK, ks1 = ks0 + X3B::CK < X3B::NKS ? ks0 + X3B::CK : X3B::NKS;
-            for (int ks = ks0; ks < ks1; ks++, off += X3B::REC2) put_record(off, c, ks);
-            if (part == 1)
-                for (int ks = 6; ks <= 7; ks++) {
+        const size_t base = L.c0_b + (size_t)(c - 1) * L.conv_b;
+        for (int part = 0; part < L.n_parts; part++) {
+            size_t off = base + L.off[part];
+            for (int ks = L.ks0[part]; ks < L.ks1[part]; ks++, off += REC2) put_record(off, c, ks);
+            for (int ks = L.ks0[part]; ks < L.ks1[part]; ks++) {
+                if (ks == 6 || ks == 7) {
                     put_t(off, c, ks);
-                    put_x(off + X3B::FR, c, ks, hi);
-                    put_x(off + 2 * X3B::FR, c, ks, lo);
-                    off += 3 * X3B::FR;
+                    put_x(off + FR, c, ks, hi);
+                    put_x(off + 2 * FR, c, ks, lo);
+                    off += 3 * FR;
+                } else if (ks == X3B::NKS - 1) {
+                    put_t(off, c, ks);
+                    off += FR;
                 }
-            if (part == 3) put_t(off, c, X3B::NKS - 1);
+            }
         }
     }
+}
+
+// Column layout of az_tower_x3d_kernel (az_tower_x3d.h) for an H x W board: boards per workgroup, row stride, cells per board
+// region, and the tables - which (board, position) is column 16 k + l15 of tile k, and for every column and tap plane the column
+// that takes its tile-X term.  Board b's cells: b R + (y + 1) rs + x + 1.  R > H rs + W keeps every tap of every position inside
+// the board or on a halo cell; (R, rs) - constants of the kernel variant - make the nb H W cells fall into the 16 residues mod 16
+// equally often; tile k takes the k-th position (in board, position order) of every residue, lane l15 the one of residue l15.
+struct X3DLayout {
+    int variant = -1, nb = 0, R = 0, rs = 0;
+    std::vector<uint16_t> pos, sdst;
+};
+static X3DLayout x3d_layout(int H, int W) {
+    X3DLayout out;
+    const int HW = H * W;
+    for (int v = 2; v < 3 && out.variant < 0; v++) { // (variants 0, 1 - 6x7- and 6x6-sized - are not instantiated: az_tower_x3d.hip)
+        const X3DVariant V = az_x3d_variant(v);
+        const int ncol = 16 * V.tiles;
+        if (ncol % HW) continue;
+        const int nb = ncol / HW;
+        // (rs, R) are compile-time constants of the kernel variant: check that they suit THIS board - every tap of every position
+        // inside the board or on a halo cell, the planes large enough, the residues flat
+        const int rs = V.rs, R = V.R;
+        if (rs < W + 1 || R < H * rs + W + 1 || (nb - 1) * R + (H + 1) * rs + W + 2 > V.pc) continue;
+        int hist[16] = {0};
+        for (int b = 0; b < nb; b++)
+            for (int pp = 0; pp < HW; pp++) hist[(b * R + (pp / W + 1) * rs + pp % W + 1) & 15]++;
+        bool flat = true;
+        for (int r = 0; r < 16; r++) flat = flat && hist[r] == V.tiles;
+        if (flat) out.variant = v, out.nb = nb, out.R = R, out.rs = rs;
+    }
+    if (out.variant < 0) return out;
+    const X3DVariant V = az_x3d_variant(out.variant);
+    const int ncol = 16 * V.tiles;
+    out.pos.assign(ncol, 0);
+    std::vector<int> col_of((size_t)out.nb * HW, -1), seen(16, 0);
+    for (int b = 0; b < out.nb; b++)
+        for (int pp = 0; pp < HW; pp++) {
+            const int r = (b * out.R + (pp / W + 1) * out.rs + pp % W + 1) & 15, k = seen[r]++;
+            out.pos[k * 16 + r] = (uint16_t)(b << 8 | pp);
+            col_of[(size_t)b * HW + pp] = k * 16 + r;
+        }
+    out.sdst.assign((size_t)ncol * 8, 0xFFFF);
+    for (int col = 0; col < ncol; col++) {
+        const int b = out.pos[col] >> 8, pp = out.pos[col] & 255, y = pp / W, x = pp % W;
+        for (int t = 0; t < 8; t++) { // plane t = tap tap_of_plane(t) with d = (dy, dx): this column's value is a term of out[position - d]
+            const int tap = X3D::tap_of_plane(t), dy = tap / 3 - 1, dx = tap % 3 - 1, yd = y - dy, xd = x - dx;
+            if (yd >= 0 && yd < H && xd >= 0 && xd < W) out.sdst[(size_t)col * 8 + t] = (uint16_t)col_of[(size_t)b * HW + yd * W + xd];
+        }
+    }
+    return out;
 }
 
 #define AZ_X3C_MAX_BOARDS 512 // (set from profiles/r3_tower_vs_boards.txt)
@@ -265,8 +355,6 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
     if (n->precision == AZ_NET_PREC_F16X3) {
         X3Geom g = x3_geom(d.rows, d.cols, d.n_filters <= 50 ? 2 : 16);
         n->x3b = g.rp1 && d.n_filters <= 50; // row-pair board, channels 48, 49 the only ones past three tiles
-        const char *tw = getenv("AZ_NET_TOWER");
-        n->x3p = !(tw && strcmp(tw, "x3b") == 0);
         if (!n->x3b && (g.nt > 4 || g.lds > 160 * 1024)) {
             g_net_err = "board / filter count does not fit the f16x3 tower kernel's LDS budget";
             delete n;
@@ -369,8 +457,20 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
             }
         };
         std::vector<unsigned char> hi, dev;
+        const char *tw = getenv("AZ_NET_TOWER");
+        if (n->precision == AZ_NET_PREC_F16X3 && d.n_filters <= 50 && !(tw && strcmp(tw, "x3b") == 0)) {
+            const X3DLayout L = x3d_layout(d.rows, d.cols);
+            if (L.variant >= 0) {
+                n->x3d = L.variant, n->xd_nb = L.nb, n->xd_R = L.R, n->xd_rs = L.rs;
+                std::vector<unsigned char> sd;
+                build_x3_stream(x3d_stream_layout(), d.conv_w, d.conv_w_lo, n_convs, sd);
+                up((void **)&n->conv_w_d, sd.data(), sd.size());
+                up((void **)&n->xd_pos, L.pos.data(), L.pos.size() * 2);
+                up((void **)&n->xd_sdst, L.sdst.data(), L.sdst.size() * 2);
+            }
+        }
         if (n->x3b) {
-            build_x3b_stream(d.conv_w, d.conv_w_lo, n_convs, dev);
+            build_x3_stream(x3b_stream_layout(), d.conv_w, d.conv_w_lo, n_convs, dev);
             up((void **)&n->conv_w, dev.data(), dev.size());
         } else {
         build_records((const unsigned char *)d.conv_w, hi);
@@ -461,17 +561,43 @@ static TowerGeom choose_geom(const az_net *n, int n_boards) {
     return g;
 }
 
+// which kernels az_net_forward launches for a batch of n_boards (the SAME conditions as there)
+struct NetDispatch {
+    bool x3c, x3c_head, x3d, f16c;
+};
+static NetDispatch net_dispatch(const az_net *n, int n_boards) {
+    NetDispatch d = {false, false, false, false};
+    const int HW = n->d.rows * n->d.cols, ksteps = HW * AZ_NET_XOUT_C / 32;
+    if (n->precision == AZ_NET_PREC_F16X3) {
+        d.x3c = n->x3b && n_boards <= AZ_X3C_MAX_BOARDS;
+        d.x3c_head = d.x3c && n->n_ot == 1 && ksteps <= 96 && n->d.cols >= 4;
+        d.x3d = !d.x3c && n->x3d >= 0;
+    } else {
+        const TowerGeom gc = tower_geom(1, 1, n->d.rows, n->d.cols);
+        d.f16c = n_boards <= AZ_F16C_MAX_BOARDS && n->r3 == 2 && gc.tpb && gc.rs == 8 && gc.tpb <= 3;
+    }
+    return d;
+}
+
 extern "C" int az_net_issued_mfma_per_board(const az_net *n, int32_t n_boards, double *out) {
     if (!n || !out || n_boards < 1) return AZ_E_INVALID;
     const int n_convs = 2 * n->d.n_blocks, nks = n->r3 < 16 ? 15 : AZ_NET_KSTEPS;
     const int HW = n->d.rows * n->d.cols;
+    const NetDispatch dp = net_dispatch(n, n_boards);
     const double head = (double)n->n_ot * (HW * AZ_NET_XOUT_C / 32) / 16.0; // one MFMA per (output tile, k-step) per 16 boards
+    // a column tile on the x3b scheme: conv 0: 4 k-steps x (9 + 2 T); then 15 x 9 + 2 x (2 T + 3 X) + 2 T (gather k-step)
+    const double per_tile = AZ_NET_K0STEPS * 11 + (double)(n_convs - 1) * (15 * 9 + 2 * 5 + 2);
     if (n->precision == AZ_NET_PREC_F16X3) {
         const X3Geom g = x3_geom(n->d.rows, n->d.cols, n->r3);
-        if (n->x3b) // per column tile: conv 0: 4 k-steps x (27 + 2 T); then 15 x 27 + 2 x (2 T + 3 X) + 2 T (gather k-step)
-            *out = 3.0 * (AZ_NET_K0STEPS * 11 + (double)(n_convs - 1) * (15 * 9 + 2 * 5 + 2)) + 3.0 * head;
+        if (dp.x3d) *out = az_x3d_variant(n->x3d).tiles * per_tile / n->xd_nb + 3.0 * head; // the workgroup's tiles over its boards
+        else if (n->x3b) // three tiles per board (x3b, x3c); the head fused into x3c runs its eight chains once per board or pair of boards
+            *out = 3.0 * per_tile + 3.0 * (dp.x3c_head ? head * 16.0 / (n_boards > AZ_X3C_ONE_PER_WG ? 2 : 1) : head);
         else
             *out = x3_mfma_per_wave(g.nt <= 3 ? 3 : 4, n_convs, nks) + 3.0 * head; // one board per wave
+        return AZ_OK;
+    }
+    if (dp.f16c) { // one board per four-wave workgroup: three column tiles x 4 output-channel tiles
+        *out = (double)(AZ_NET_K0STEPS + (n_convs - 1) * nks) * 4 * 3 + head;
         return AZ_OK;
     }
     const TowerGeom g = choose_geom(n, n_boards);
@@ -480,13 +606,18 @@ extern "C" int az_net_issued_mfma_per_board(const az_net *n, int32_t n_boards, d
     return AZ_OK;
 }
 
-extern "C" const char *az_net_kernel_label(const az_net *n) {
+extern "C" const char *az_net_kernel_label(const az_net *n, int32_t n_boards) {
     if (!n) return "";
     const bool big = n->n_ot > OTG;
+    const NetDispatch dp = net_dispatch(n, n_boards < 1 ? n->max_boards : n_boards);
     if (n->precision == AZ_NET_PREC_F16X3) {
+        if (dp.x3c_head) return "az_tower_x3c_kernel (fc1 + softmax + tanh in the same launch)";
+        if (dp.x3c) return big ? "az_tower_x3c_kernel + az_head_logits_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3c_kernel + az_head_kernel<X3>";
+        if (dp.x3d) return big ? "az_tower_x3d_kernel + az_head_logits_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3d_kernel + az_head_kernel<X3>";
         if (n->x3b) return big ? "az_tower_x3b_kernel + az_head_logits_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3b_kernel + az_head_kernel<X3>";
         return big ? "az_tower_x3_kernel + az_head_logits_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3_kernel + az_head_kernel<X3>";
     }
+    if (dp.f16c) return big ? "az_tower_f16c_kernel + az_head_logits_kernel + az_head_softmax_kernel" : "az_tower_f16c_kernel + az_head_kernel";
     return big ? "az_tower_kernel + az_head_logits_kernel + az_head_softmax_kernel" : "az_tower_kernel + az_head_kernel";
 }
 
@@ -537,12 +668,13 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         tp.xout = n->xout;
         tp.xout_lo = n->xout_lo;
         const int grid = (n_boards + 3) / 4;
-        const bool x3c = n->x3b && n_boards <= AZ_X3C_MAX_BOARDS; // small batch: one board per workgroup (az_tower_x3c.h)
+        const NetDispatch dp = net_dispatch(n, n_boards);
+        const bool x3c = dp.x3c; // small batch: one board per workgroup (az_tower_x3c.h)
         // ... and with a single output tile (connect_four: 7 + 1 outputs) that kernel also runs fc1 + softmax + tanh for its board:
         // at <= 512 boards the head kernel is 7 us of a 49 us tick (profiles/r3_small_generation_kernel_stats.csv).  (The same inside
         // az_tower_x3b_kernel, measured: bit-identical and SLOWER - 1146 vs 1182 games/s in a same-box A/B: at one workgroup per CU
         // the head phase of each of the four rounds, ~5 us, has nothing to hide behind.)
-        const bool fused_head = x3c && n->n_ot == 1 && hp.ksteps <= 96 && n->d.cols >= 4; // (eight chains x HMAX k-steps; a chain steps 4 columns: az_tower_x3c.h)
+        const bool fused_head = dp.x3c_head; // (eight chains x HMAX k-steps; a chain steps 4 columns: az_tower_x3c.h)
         tp.fc_w = fused_head ? n->fc_w : nullptr;
         tp.fc_w_lo = n->fc_w_lo;
         tp.fc_b = n->fc_b;
@@ -550,9 +682,15 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         tp.values = values;
         tp.A = n->d.num_actions;
         tp.fc_ksteps = hp.ksteps;
-        hipError_t s = x3c ? az_launch_tower_x3c(n->d.device, n_boards > AZ_X3C_ONE_PER_WG ? 2 : 1, tp, n_boards, st)
-                       : n->x3b ? (n->x3p ? az_launch_tower_x3p(n->d.device, tp, grid, st) : az_launch_tower_x3b(n->d.device, tp, grid, st))
-                              : az_launch_tower_x3(n->d.device, g.nt, g.rp1, n->r3, tp, grid, g.lds, st);
+        hipError_t s;
+        if (x3c) s = az_launch_tower_x3c(n->d.device, n_boards > AZ_X3C_ONE_PER_WG ? 2 : 1, tp, n_boards, st);
+        else if (dp.x3d) { // packed column tiles (az_tower_x3d.h)
+            tp.conv_w = n->conv_w_d;
+            tp.xd_nb = n->xd_nb, tp.xd_R = n->xd_R, tp.xd_rs = n->xd_rs;
+            tp.xd_pos = n->xd_pos, tp.xd_sdst = n->xd_sdst;
+            s = az_launch_tower_x3d(n->d.device, n->x3d, tp, (n_boards + n->xd_nb - 1) / n->xd_nb, st);
+        } else if (n->x3b) s = az_launch_tower_x3b(n->d.device, tp, grid, st);
+        else s = az_launch_tower_x3(n->d.device, g.nt, g.rp1, n->r3, tp, grid, g.lds, st);
         if (s != hipSuccess) {
             n->err = std::string("f16x3 tower launch: ") + hipGetErrorString(s);
             return AZ_E_HIP;
@@ -589,7 +727,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     hipError_t s;
     // small batch of a row-pair board with <= 50 filters: a board per four-wave workgroup (az_tower_f16c.h; same bits)
     const TowerGeom gc = tower_geom(1, 1, n->d.rows, n->d.cols);
-    if (n_boards <= AZ_F16C_MAX_BOARDS && n->r3 == 2 && gc.tpb && gc.rs == 8 && gc.tpb <= 3) {
+    if (net_dispatch(n, n_boards).f16c) {
         // up to a board per CU: 32 KiB weight chunks (half the barriers); above: 16 KiB chunks, so that two workgroups fit a CU's LDS
         const int ck = n_boards <= AZ_X3C_ONE_PER_WG ? 8 : 4;
         tp.cells = gc.cells, tp.rs = gc.rs, tp.tpb = gc.tpb;

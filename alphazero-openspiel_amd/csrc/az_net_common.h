@@ -39,6 +39,10 @@ struct TowerParams {
     const float *fc_b;
     float *priors, *values;
     int A, fc_ksteps;
+    // az_tower_x3d_kernel only (az_tower_x3d.h): packed, permuted column tiles of xd_nb boards per workgroup
+    int xd_nb, xd_R, xd_rs;       // boards per workgroup; cells per board region; row stride (cell = b R + (y + 1) rs + x + 1)
+    const uint16_t *xd_pos;       // [16 x tiles] column -> board << 8 | position
+    const uint16_t *xd_sdst;      // [16 x tiles][8] column, tap plane t -> the column that takes this column's tile-X term (0xFFFF: off the board)
 };
 
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.01f * v); }
@@ -89,6 +93,18 @@ __device__ __forceinline__ void launder(half8 &v) { asm volatile("" : "+v"(v)); 
 __device__ __forceinline__ void launder(f32x4 &v) { asm volatile("" : "+v"(v)); }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void launder(f32x2 &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void launder_u(unsigned &v) { asm volatile("" : "+v"(v)); }
+// A kernel whose accumulators live in AGPRs (more than 256 registers per lane): the value an MFMA leaves there is copied to a
+// VGPR for the epilogue's vector arithmetic, and the register allocator puts that copy right behind the MFMA - in the last k-step
+// every MFMA is then followed by the wait for its own result.  pin_acc(x), placed behind the k-loop, keeps x in its AGPR until there.
+__device__ __forceinline__ void pin_acc(f32x4 &v) { asm volatile("" : "+a"(v)); }
+// an address sum the compiler must not hoist out of the conv loop (it is invariant there: hoisted, every (tile, k-step) pair of
+// az_tower_x3d_kernel would hold a register for the whole kernel)
+__device__ __forceinline__ unsigned addr_add(unsigned a, unsigned b) {
+    unsigned r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // untracked 8-byte LDS accesses (volatile asms keep their program order; LDS executes one wave's operations in order)
 template <int OFF> __device__ __forceinline__ void lds_read64_off(f32x2 &dst, unsigned lds_byte_addr) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
@@ -126,6 +142,30 @@ struct X3B {
 };
 static_assert(X3B::LDS <= 160 * 1024, "x3b LDS budget");
 static_assert(X3B::C0_B <= X3B::CHUNK_S, "conv 0 must fit a chunk buffer");
+
+// Geometry of az_tower_x3d_kernel (az_tower_x3d.h): the weight stream in 3-k-step chunks (two 18-KiB LDS buffers leave room for the
+// planes of eight connect_four boards), the fixed part of the LDS map.  Shared with the host packing in az_net.hip.
+//   conv 0:      part 0: k-steps 0, 1, then T of each | part 1: k-steps 2, 3, then T of each
+//   conv c >= 1: parts [0,3) [3,6) [6,8) + (T, Xhi, Xlo) of k-steps 6, 7 | [8,11) [11,14) [14] + T of the gather k-step
+constexpr int x3d_part_ks0(int part) { return part == 0 ? 0 : part == 1 ? 3 : part == 2 ? 6 : part == 3 ? 8 : part == 4 ? 11 : 14; }
+constexpr int x3d_part_len(int part) { return part == 2 ? 2 : part == 5 ? 1 : 3; }
+constexpr int x3d_part_bytes(int part) { return x3d_part_len(part) * 6144 + (part == 2 ? 6 * 1024 : part == 5 ? 1024 : 0); }
+constexpr int x3d_part_off(int part) { return part == 0 ? 0 : x3d_part_off(part - 1) + x3d_part_bytes(part - 1); }
+struct X3D {
+    static constexpr int FR = 1024, REC2 = 6 * FR, NKS = 15, PARTS = 6, PARTS0 = 2;
+    static constexpr int part_ks0(int part) { return x3d_part_ks0(part); }
+    static constexpr int part_len(int part) { return x3d_part_len(part); }
+    static constexpr int part_of(int ks) { return ks < 3 ? 0 : ks < 6 ? 1 : ks < 8 ? 2 : ks < 11 ? 3 : ks < 14 ? 4 : 5; }
+    static constexpr int part_bytes(int part) { return x3d_part_bytes(part); }
+    static constexpr int part_off(int part) { return x3d_part_off(part); }
+    static constexpr int CONV_B = x3d_part_off(5) + x3d_part_bytes(5);
+    static constexpr int C0_PART_B = 2 * REC2 + 2 * FR, C0_B = 2 * C0_PART_B;
+    static constexpr int CHUNK_S = 3 * REC2;            // LDS stride of the two chunk buffers (the largest part)
+    static constexpr int OFF_EPI = 2 * CHUNK_S;         // epilogue ring (2 KiB) + trash slots (16 B per thread)
+    static constexpr int OFF_S = OFF_EPI + 2048 + 256 * 16; // scratch: [9 tap planes][columns][2 channels] fp32
+    static constexpr int tap_of_plane(int t) { return t < 4 ? t : t + 1; }
+};
+static_assert(x3d_part_bytes(2) <= X3D::CHUNK_S && X3D::C0_PART_B <= X3D::CHUNK_S && X3D::CONV_B == 15 * 6144 + 7 * 1024, "every part fits a chunk buffer");
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {

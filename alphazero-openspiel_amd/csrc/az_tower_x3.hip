@@ -4,7 +4,6 @@
 #include "az_tower_x3.h"
 #include "az_tower_x3b.h"
 #include "az_tower_x3c.h"
-#include "az_tower_x3p.h"
 
 template <int NT, bool RP1, int R3> static hipError_t launch_r3(int dv, const TowerParams &tp, int grid, int lds, hipStream_t st) {
     static bool attr_set[AZ_MAX_DEVICES] = {false};
@@ -32,17 +31,6 @@ hipError_t az_launch_tower_x3b(int device, const TowerParams &tp, int grid, hipS
         if (device >= 0 && device < AZ_MAX_DEVICES) attr_set[device] = true;
     }
     hipLaunchKernelGGL((az_tower_x3b_kernel<3>), dim3(grid), dim3(256), X3B::LDS, st, tp);
-    return hipGetLastError();
-}
-
-hipError_t az_launch_tower_x3p(int device, const TowerParams &tp, int grid, hipStream_t st) {
-    static bool attr_set[AZ_MAX_DEVICES] = {false};
-    if (device < 0 || device >= AZ_MAX_DEVICES || !attr_set[device]) {
-        hipError_t s = hipFuncSetAttribute((const void *)az_tower_x3p_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (s != hipSuccess) return s;
-        if (device >= 0 && device < AZ_MAX_DEVICES) attr_set[device] = true;
-    }
-    hipLaunchKernelGGL((az_tower_x3p_kernel<3>), dim3(grid), dim3(512), X3B::LDS, st, tp);
     return hipGetLastError();
 }
 

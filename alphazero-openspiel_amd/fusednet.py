@@ -292,8 +292,9 @@ class FusedNet:
         self._check(self.lib.az_net_issued_mfma_per_board(self._h, int(n_boards or self.max_boards), C.byref(out)))
         return out.value
 
-    def kernel_label(self):
-        return self.lib.az_net_kernel_label(self._h).decode()
+    def kernel_label(self, n_boards=None):
+        """Names of the kernels a forward of n_boards boards launches (default: the reserved maximum)."""
+        return self.lib.az_net_kernel_label(self._h, int(n_boards or self.max_boards)).decode()
 
     def read_tower(self, n_boards):
         out = np.zeros((n_boards, self.packed["rows"] * self.packed["cols"], XOUT_C), dtype=np.float32)

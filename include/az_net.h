@@ -85,9 +85,10 @@ int az_net_read_tower(az_net *n, float *out, int32_t n_boards);
  * (the work partition depends on the batch size).  Host arithmetic only; touches no device. */
 int az_net_issued_mfma_per_board(const az_net *n, int32_t n_boards, double *out);
 
-/* Names of the kernels az_net_forward launches for this net ("az_tower_x3b_kernel + az_head_kernel<X3>", ...): labels for
- * bench.py's roofline object and for matching rocprofv3 rows.  Static storage. */
-const char *az_net_kernel_label(const az_net *n);
+/* Names of the kernels az_net_forward launches for a batch of n_boards boards of this net ("az_tower_x3b_kernel +
+ * az_head_kernel<X3>", ...; the choice depends on the batch size, like the count above; n_boards < 1: the reserved maximum):
+ * labels for bench.py's roofline object and for matching rocprofv3 rows.  Static storage. */
+const char *az_net_kernel_label(const az_net *n, int32_t n_boards);
 
 #ifdef __cplusplus
 }

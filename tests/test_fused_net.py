@@ -194,11 +194,13 @@ def test_fused_f32x_forward_is_fp32_grade(tag, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["c4_10block", "bt6_10block", "bt5x4_3block"])
+@pytest.mark.parametrize("tag", ["c4_10block", "bt6_10block", "bt5x4_3block", "bt8_2block"])
 def test_fused_f32x_outputs_do_not_depend_on_the_batch_size(tag):
     """The fp32-grade tower has a board-per-wave kernel (az_tower_x3b_kernel, > 512 boards) and a board-per-workgroup kernel for
     small batches (az_tower_x3c_kernel: the four waves split a board by output-channel tile): priors, value and tower output of
-    a board must be the same BITS in both - a generation's records may not depend on when its tail switches kernels."""
+    a board must be the same BITS in both - a generation's records may not depend on when its tail switches kernels.  8x8 boards
+    run az_tower_x3d_kernel (four boards packed into 16 column tiles, eight waves) at every batch size: which boards share a
+    workgroup, and ragged last workgroups, must not show either."""
     game, net = _nets()[tag]
     fn = fusednet.FusedNet(net, "cuda:0", max_boards=1024, precision="f32x")
     torch.manual_seed(5)
@@ -206,7 +208,8 @@ def test_fused_f32x_outputs_do_not_depend_on_the_batch_size(tag):
     ref_p, ref_v = [t.clone() for t in fn.forward(obs)]
     torch.cuda.synchronize()
     ref_t = fn.read_tower(1024)
-    assert "x3b" in fn.kernel_label()
+    assert ("x3d" if tag.startswith("bt8") else "x3b") in fn.kernel_label(1024)
+    assert tag.startswith("bt8") or "x3c" in fn.kernel_label(300)
     for n in (700, 512, 300, 256, 64, 5, 1):
         p, v = fn.forward(obs[:n].contiguous())
         torch.cuda.synchronize()
