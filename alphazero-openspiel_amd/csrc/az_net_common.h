@@ -98,6 +98,31 @@ __device__ __forceinline__ void launder_u(unsigned &v) { asm volatile("" : "+v"(
 // VGPR for the epilogue's vector arithmetic, and the register allocator puts that copy right behind the MFMA - in the last k-step
 // every MFMA is then followed by the wait for its own result.  pin_acc(x), placed behind the k-loop, keeps x in its AGPR until there.
 __device__ __forceinline__ void pin_acc(f32x4 &v) { asm volatile("" : "+a"(v)); }
+// (x0, x1) -> the packed fp16 pairs (hi0, hi1) and (lo0, lo1) of the split-fp16 format: hi = fp16(x) (round to nearest even),
+// lo = fp16((x - hi) * 2048), computed as fma(hi, -2048, x * 2048) - x * 2048 and the fma's result are exact (hi is x rounded to
+// 11 bits: the difference has at most 13), so these are the bits of the subtract-then-scale form.  Five instructions for two
+// values (v_cvt_pk_f16_f32, two multiplies, v_fma_mixlo / mixhi_f16 reading the fp16 operand in place and writing the fp16
+// result directly) against the twelve hipcc emits for the plain C++ expression.
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, unsigned &lo) {
+    const float m = -2048.0f, t0 = x0 * 2048.0f, t1 = x1 * 2048.0f;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(lo) : "v"(hi), "v"(m), "v"(t0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(m), "v"(t1));
+}
+// four values at once (the fp32-grade towers' epilogues)
+__device__ __forceinline__ void split4_f16x3(const f32x4 &v, half4 &hi, half4 &lo) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned h0, h1, l0, l1;
+    split_pair(v[0], v[1], h0, l0);
+    split_pair(v[2], v[3], h1, l1);
+    hi = __builtin_bit_cast(half4, (u32x2){h0, h1});
+    lo = __builtin_bit_cast(half4, (u32x2){l0, l1});
+}
+// a + a2 / 2048 in one rounding: a2 / 2048 is exact (a power of two), so fma(a2, 1/2048, a) has the bits of multiply-then-add
+__device__ __forceinline__ f32x4 comb_f16x3(const f32x4 &a, const f32x4 &a2) {
+    const f32x4 is = {1.0f / 2048.0f, 1.0f / 2048.0f, 1.0f / 2048.0f, 1.0f / 2048.0f};
+    return __builtin_elementwise_fma(a2, is, a);
+}
 // an address sum the compiler must not hoist out of the conv loop (it is invariant there: hoisted, every (tile, k-step) pair of
 // az_tower_x3d_kernel would hold a register for the whole kernel)
 __device__ __forceinline__ unsigned addr_add(unsigned a, unsigned b) {

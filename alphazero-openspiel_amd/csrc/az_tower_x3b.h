@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int WAVES = 4, FR = X3B::FR, REC2 = X3B::REC2, CK = X3B::CK, NKS = X3B::NKS, PARTS = X3B::PARTS;
     constexpr int CHUNK_S = X3B::CHUNK_S, LO_OFF = X3B::LO_OFF, S_PLANE = X3B::S_PLANE;
-    constexpr float INV_SPLIT = 1.0f / 2048.0f, SPLIT = 2048.0f;
+    constexpr float INV_SPLIT = 1.0f / 2048.0f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l15 = lane & 15;
     constexpr int plane_b = X3B::PLANE_B;
@@ -82,10 +82,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
     const unsigned sread = lds_base + s_wave + l15 * 8; // plane t, tile nt: + t * S_PLANE + nt * 128
 
     // x -> (hi, lo): hi = fp16(x), lo = fp16((x - hi) * 2048)
-    auto split4 = [&](const f32x4 &v, half4 &hi, half4 &lo) {
-        hi = __builtin_convertvector(v, half4);
-        lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * SPLIT, half4);
-    };
+    auto split4 = [&](const f32x4 &v, half4 &hi, half4 &lo) { split4_f16x3(v, hi, lo); }; // (five instructions per pair: az_net_common.h)
 
     f32x4 acc[4][NT], acc2[4][NT], xres[4][NT]; // [3]: tile T
     f32x4 accxh[NT], accxl[NT];                 // tile X
@@ -226,9 +223,9 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
             if constexpr (IS_FIRST) return;
             if constexpr (ks == 8 && j < 9 * NT) { // 9 slots per column tile: 4 combine, 2 centre, 3 stores
                 constexpr int nt = j / 9, i = j % 9;
-                if constexpr (i < 4) xv[i] = accxh[nt][i] + accxl[nt][i] * INV_SPLIT;
+                if constexpr (i < 4) xv[i] = __builtin_fmaf(accxl[nt][i], INV_SPLIT, accxh[nt][i]); // (= accxh + accxl / 2048, bit for bit: the scaling is exact)
                 else if constexpr (i < 6) // (lanes q == 1 hold rows 4..7 of tile T: hi c0, hi c1, lo c0, lo c1 of the centre tap)
-                    cv[i - 4] = acc[3][nt][i - 4] + (acc[3][nt][i - 2] + acc2[3][nt][i - 4]) * INV_SPLIT;
+                    cv[i - 4] = __builtin_fmaf(acc[3][nt][i - 2] + acc2[3][nt][i - 4], INV_SPLIT, acc[3][nt][i - 4]);
                 else if constexpr (i == 6) lds_write64(lds_base + sdst[nt][0], (f32x2){xv[0], xv[1]});
                 else if constexpr (i == 7) lds_write64(lds_base + sdst[nt][1], (f32x2){xv[2], xv[3]});
                 else lds_write64(lds_base + scen[nt], cv);
@@ -272,6 +269,11 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
                                                      (__attribute__((address_space(3))) void *)(lds + X3B::OFF_EPI + (conv & 1) * 1024), 16, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!IS_FIRST && ks == 8) // (tile X is final: keep it in its AGPRs until the scratch path reads it, below)
+                static_for<NT>([&](auto nt_c) {
+                    pin_acc(accxh[decltype(nt_c)::value]);
+                    pin_acc(accxl[decltype(nt_c)::value]);
+                });
             if constexpr (last_of_conv)
                 static_for<4>([&](auto mt_c) {
                     constexpr int mt = decltype(mt_c)::value;
@@ -357,6 +359,17 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
             }
             launder(ep_nb[mt]);
         });
+        // The accumulators live in AGPRs (the kernel holds ~470 registers), the epilogue's arithmetic needs them in VGPRs, and left to
+        // itself the register allocator makes that copy right behind the MFMA that produces the final value: every MFMA of the last
+        // k-step was followed by the wait for its own result (s_nop 7 + four v_accvgpr_read_b32, 33 times per conv).  Pinned in their
+        // AGPRs here, the values are copied where the epilogue uses them - long after the MFMAs have drained.
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                pin_acc(acc[mt][nt]);
+                pin_acc(acc2[mt][nt]);
+            }
         // ---- epilogue, in fp32; the result is split into (hi, lo) again ------------------------------------------
         auto epilogue = [&](auto kind) {
             constexpr int KIND = decltype(kind)::value; // 0: conv1, 1: conv2 (not last), 2: last conv
@@ -369,11 +382,11 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
                 for (int nt = 0; nt < NT; nt++) {
                     f32x4 v;
                     if (mt < 3) {
-                        v = acc[mt][nt] + acc2[mt][nt] * INV_SPLIT;
+                        v = comb_f16x3(acc[mt][nt], acc2[mt][nt]);
                         acc[mt][nt] = next_bias;
                     } else { // tile T, lanes q == 0: rows hi 48, hi 49, lo 48, lo 49 of the gather k-step (+ bias), plus the tap planes
-                        v = (f32x4){acc[3][nt][0] + (acc[3][nt][2] + acc2[3][nt][0]) * INV_SPLIT,
-                                    acc[3][nt][1] + (acc[3][nt][3] + acc2[3][nt][1]) * INV_SPLIT, 0.f, 0.f};
+                        v = (f32x4){__builtin_fmaf(acc[3][nt][2] + acc2[3][nt][0], INV_SPLIT, acc[3][nt][0]),
+                                    __builtin_fmaf(acc[3][nt][3] + acc2[3][nt][1], INV_SPLIT, acc[3][nt][1]), 0.f, 0.f};
                         if constexpr (!IS_FIRST) {
                             v[0] += s49[nt][0];
                             v[1] += s49[nt][1];

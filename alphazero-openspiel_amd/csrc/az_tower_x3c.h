@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int WAVES = 4 * BPW, FR = X3B::FR, REC2 = X3B::REC2, CK = X3B::CK, NKS = X3B::NKS, PARTS = X3B::PARTS;
     constexpr int CHUNK_S = X3B::CHUNK_S, LO_OFF = X3B::LO_OFF, S_PLANE = X3B::S_PLANE;
-    constexpr float INV_SPLIT = 1.0f / 2048.0f, SPLIT = 2048.0f;
+    constexpr float INV_SPLIT = 1.0f / 2048.0f;
     constexpr int plane_b = X3B::PLANE_B;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l15 = lane & 15;
@@ -60,10 +60,7 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
     int (&pos_addr)[NT] = T.pos_addr, (&grow)[NT] = T.grow, (&p6_addr)[NT] = T.p6_addr;
     int (&koff)[AZ_NET_KSTEPS] = T.koff, (&ksp)[4] = T.ksp, (&koff0)[AZ_NET_K0STEPS] = T.koff0;
 
-    auto split4 = [&](const f32x4 &v, half4 &hi, half4 &lo) {
-        hi = __builtin_convertvector(v, half4);
-        lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * SPLIT, half4);
-    };
+    auto split4 = [&](const f32x4 &v, half4 &hi, half4 &lo) { split4_f16x3(v, hi, lo); };
     __syncthreads(); // the zeroes are down before wave 0 writes the input planes
 
     // ---- weight stream (az_tower_x3b.h): chunk c -> buffer c & 1; the four waves issue a chunk's pieces together
@@ -314,10 +311,10 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
                     for (int nt = 0; nt < NT; nt++) {
                         f32x4 xv;
 #pragma unroll
-                        for (int i = 0; i < 4; i++) xv[i] = accxh[nt][i] + accxl[nt][i] * INV_SPLIT;
+                        for (int i = 0; i < 4; i++) xv[i] = __builtin_fmaf(accxl[nt][i], INV_SPLIT, accxh[nt][i]);
                         f32x2 cv;
 #pragma unroll
-                        for (int i = 0; i < 2; i++) cv[i] = acc[nt][i] + (acc[nt][i + 2] + acc2[nt][i]) * INV_SPLIT;
+                        for (int i = 0; i < 2; i++) cv[i] = __builtin_fmaf(acc[nt][i + 2] + acc2[nt][i], INV_SPLIT, acc[nt][i]);
                         lds_write64(lds_base + sdst[nt][0], (f32x2){xv[0], xv[1]});
                         lds_write64(lds_base + sdst[nt][1], (f32x2){xv[2], xv[3]});
                         lds_write64(lds_base + scen[nt], cv);
@@ -359,10 +356,10 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
                 for (int nt = 0; nt < NT; nt++) {
                     f32x4 v;
                     if constexpr (!TX) {
-                        v = acc[nt] + acc2[nt] * INV_SPLIT;
+                        v = comb_f16x3(acc[nt], acc2[nt]);
                         acc[nt] = next_bias;
                     } else {
-                        v = (f32x4){acc[nt][0] + (acc[nt][2] + acc2[nt][0]) * INV_SPLIT, acc[nt][1] + (acc[nt][3] + acc2[nt][1]) * INV_SPLIT, 0.f, 0.f};
+                        v = (f32x4){__builtin_fmaf(acc[nt][2] + acc2[nt][0], INV_SPLIT, acc[nt][0]), __builtin_fmaf(acc[nt][3] + acc2[nt][1], INV_SPLIT, acc[nt][1]), 0.f, 0.f};
                         if constexpr (!IS_FIRST) {
                             v[0] += s49[nt][0];
                             v[1] += s49[nt][1];

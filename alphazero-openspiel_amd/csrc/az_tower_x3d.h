@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
     using VV = X3DV<V>;
     constexpr int WAVES = 8, NKS = X3D::NKS, PARTS = X3D::PARTS;
     constexpr int CHUNK_S = X3D::CHUNK_S, LO_OFF = G::LO_OFF, S_PLANE = G::S_PLANE, plane_b = G::PLANE_B;
-    constexpr float INV_SPLIT = 1.0f / 2048.0f, SPLIT = 2048.0f;
+    constexpr float INV_SPLIT = 1.0f / 2048.0f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l15 = lane & 15;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
@@ -130,10 +130,8 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
     };
     auto sel4 = [](int qq, int c0, int c1, int c2, int c3) { return qq == 0 ? c0 : qq == 1 ? c1 : qq == 2 ? c2 : c3; };
 
-    auto split4 = [&](const f32x4 &v, half4 &hi, half4 &lo) { // x -> (hi, lo): hi = fp16(x), lo = fp16((x - hi) * 2048)
-        hi = __builtin_convertvector(v, half4);
-        lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * SPLIT, half4);
-    };
+    auto split4 = [&](const f32x4 &v, half4 &hi, half4 &lo) { split4_f16x3(v, hi, lo); }; // x -> (hi, lo): az_net_common.h
+    auto comb4 = [&](const f32x4 &a, const f32x4 &a2) { return comb_f16x3(a, a2); };      // a + a2 / 2048
     __syncthreads(); // the zeroes are down before the input planes are written
 
     // ---- weight stream: chunk -> buffer chunk & 1 by LDS-DMA (global_load_lds, one KiB per wave-instruction)
@@ -341,30 +339,31 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                 if constexpr (S_STORE) {
 #pragma unroll
                     for (int nt = 0; nt < NTT; nt++) {
-                        f32x4 xv;
-#pragma unroll
-                        for (int i = 0; i < 4; i++) xv[i] = accxh[nt][i] + accxl[nt][i] * INV_SPLIT;
+                        const f32x4 xv = comb4(accxh[nt], accxl[nt]);
                         f32x2 cv; // (lanes q == 1 hold rows 4..7 of tile T: hi c0, hi c1, lo c0, lo c1 of the centre tap)
 #pragma unroll
-                        for (int i = 0; i < 2; i++) cv[i] = accT[nt][i] + (accT[nt][i + 2] + acc2T[nt][i]) * INV_SPLIT;
+                        for (int i = 0; i < 2; i++) cv[i] = __builtin_fmaf(accT[nt][i + 2] + acc2T[nt][i], INV_SPLIT, accT[nt][i]);
                         lds_write64(lds_base + sdst[nt][0], (f32x2){xv[0], xv[1]});
                         lds_write64(lds_base + sdst[nt][1], (f32x2){xv[2], xv[3]});
                         lds_write64(lds_base + scen[nt], cv);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
-                if constexpr (S_SUM) {
+                if constexpr (S_SUM) { // all the tiles' reads first, one wait per tile (counted: the later tiles' reads are still in flight)
+                    f32x2 pl[NTT][9];
                     static_for<NTT>([&](auto nt_c) {
                         constexpr int nt = decltype(nt_c)::value;
                         const unsigned sread = lds_base + X3D::OFF_S + (tile[nt] * 16 + l15) * 8;
-                        f32x2 pl[9];
-                        static_for<9>([&](auto t_c) { lds_read64_off<decltype(t_c)::value * S_PLANE>(pl[decltype(t_c)::value], sread); });
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        static_for<9>([&](auto t_c) { launder(pl[decltype(t_c)::value]); });
-                        f32x2 s = pl[0];
+                        static_for<9>([&](auto t_c) { lds_read64_off<decltype(t_c)::value * S_PLANE>(pl[nt][decltype(t_c)::value], sread); });
+                    });
+                    static_for<NTT>([&](auto nt_c) {
+                        constexpr int nt = decltype(nt_c)::value;
+                        wait_lgkm(9 * (NTT - 1 - nt) < 15 ? 9 * (NTT - 1 - nt) : 15);
+                        static_for<9>([&](auto t_c) { launder(pl[nt][decltype(t_c)::value]); });
+                        f32x2 sm = pl[nt][0];
 #pragma unroll
-                        for (int t = 1; t < 9; t++) s = s + pl[t];
-                        s49[nt] = s;
+                        for (int t = 1; t < 9; t++) sm = sm + pl[nt][t];
+                        s49[nt] = sm;
                     });
                 }
                 const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -459,10 +458,10 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                 const int woff = (2 * mt + (q >> 1)) * plane_b + (q & 1) * 8;
                 f32x4 v;
                 if constexpr (!TT) {
-                    v = a + a2 * INV_SPLIT;
+                    v = comb4(a, a2);
                     a = next_bias;
                 } else { // lanes q == 0: rows hi 48, hi 49, lo 48, lo 49 of the gather k-step (+ bias), plus the tap planes
-                    v = (f32x4){a[0] + (a[2] + a2[0]) * INV_SPLIT, a[1] + (a[3] + a2[1]) * INV_SPLIT, 0.f, 0.f};
+                    v = (f32x4){__builtin_fmaf(a[2] + a2[0], INV_SPLIT, a[0]), __builtin_fmaf(a[3] + a2[1], INV_SPLIT, a[1]), 0.f, 0.f};
                     if constexpr (!IS_FIRST) {
                         v[0] += s[0];
                         v[1] += s[1];
