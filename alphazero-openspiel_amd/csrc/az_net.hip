@@ -278,7 +278,7 @@ struct X3DLayout {
 static X3DLayout x3d_layout(int H, int W) {
     X3DLayout out;
     const int HW = H * W;
-    for (int v = 2; v < 3 && out.variant < 0; v++) { // (variants 0, 1 - 6x7- and 6x6-sized - are not instantiated: az_tower_x3d.hip)
+    for (int v = 1; v < 3 && out.variant < 0; v++) { // (variants 0, 1 - 6x7- and 6x6-sized - are not instantiated: az_tower_x3d.hip)
         const X3DVariant V = az_x3d_variant(v);
         const int ncol = 16 * V.tiles;
         if (ncol % HW) continue;
@@ -571,7 +571,9 @@ static NetDispatch net_dispatch(const az_net *n, int n_boards) {
     if (n->precision == AZ_NET_PREC_F16X3) {
         d.x3c = n->x3b && n_boards <= AZ_X3C_MAX_BOARDS;
         d.x3c_head = d.x3c && n->n_ot == 1 && ksteps <= 96 && n->d.cols >= 4;
-        d.x3d = !d.x3c && n->x3d >= 0;
+        // packed tiles put xd_nb boards in a workgroup: with eight (6x6) a batch must be large enough to occupy the chip - at 1024
+        // boards 128 workgroups of 4.5 tiles per SIMD lose to 256 of 3 (az_tower_x3b_kernel, one round), from 1280 on they win
+        d.x3d = !d.x3c && n->x3d >= 0 && (!n->x3b || n_boards > 128 * n->xd_nb);
     } else {
         const TowerGeom gc = tower_geom(1, 1, n->d.rows, n->d.cols);
         d.f16c = n_boards <= AZ_F16C_MAX_BOARDS && n->r3 == 2 && gc.tpb && gc.rs == 8 && gc.tpb <= 3;

@@ -153,12 +153,13 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                                          (__attribute__((address_space(3))) void *)(lds + X3D::OFF_EPI), 16, 0, 0);
 
     // NTW: tiles the wave owns whole; EX: its share of a split tile - 0 none, 1 an output-channel tile (mt = emt), 2 tiles T and X
-    auto body = [&](auto ntw_c, auto ex_c) {
+    auto body = [&](auto ntw_c, auto ex_c, auto emt_c) {
         constexpr int NTW = decltype(ntw_c)::value, EX = decltype(ex_c)::value;
         constexpr bool EXM = EX == 1, EXT = EX == 2;
         constexpr int NTA = NTW + (EX ? 1 : 0);  // tiles whose B fragments the wave reads
         constexpr int NTT = NTW + (EXT ? 1 : 0); // tiles whose T and X this wave holds
-        const int emt = VV::split_unit(wave);     // (EXM) which output-channel tile of the split tile
+        constexpr int emt = decltype(emt_c)::value; // (EXM) which output-channel tile of the split tile: a compile-time constant - selecting
+                                                    // ah[cur][emt] by a run-time branch per MFMA cost the register allocator 45 spilled registers
         // ---- per-lane tables: the wave's tiles (nt < NTW: its own; nt = NTW: the split one) ----------------------------------
         int tile[NTA];
         unsigned baseL[NTA]; // LDS address of the lane's cell in octet plane 0 (hi)
@@ -411,15 +412,13 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                                 if constexpr (pass == 0) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, ks == 0 ? zero4 : acc2[mt][nt], 0, 0, 0);
                                 else if constexpr (pass == 1) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acc[mt][nt], 0, 0, 0);
                                 else acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, acc2[mt][nt], 0, 0, 0);
-                            } else { // the split tile's output-channel tile mt = emt (uniform branch)
+                            } else { // the split tile's output-channel tile mt = emt
                                 auto one = [&](const half8 &a_hi, const half8 &a_lo) {
                                     if constexpr (pass == 0) acc2e = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, ks == 0 ? zero4 : acc2e, 0, 0, 0);
                                     else if constexpr (pass == 1) acce = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acce, 0, 0, 0);
                                     else acc2e = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, acc2e, 0, 0, 0);
                                 };
-                                if (emt == 0) one(ah[cur][0], al[cur][0]);
-                                else if (emt == 1) one(ah[cur][1], al[cur][1]);
-                                else one(ah[cur][2], al[cur][2]);
+                                one(ah[cur][emt], al[cur][emt]);
                             }
                         } else if constexpr (j < n_main + n_t) { // tile T: x B_hi -> accT (hi rows: hi*hi, lo rows: lo*hi), x B_lo -> acc2T (hi rows: hi*lo)
                             if constexpr (j == n_main) accT[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at, b_hi, accT[nt], 0, 0, 0);
@@ -549,11 +548,15 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
     constexpr auto I2 = std::integral_constant<int, 2>{};
     constexpr auto I3 = std::integral_constant<int, 3>{};
     if constexpr (V == 0) {
-        if (wave < 4) body(I3, I0);
-        else if (wave < 7) body(I2, I1);
-        else body(I2, I2);
+        if (wave < 4) body(I3, I0, I0);
+        else if (wave == 4) body(I2, I1, I0);
+        else if (wave == 5) body(I2, I1, I1);
+        else if (wave == 6) body(I2, I1, I2);
+        else body(I2, I2, I0);
     } else if constexpr (V == 1) {
-        if ((wave & 3) < 3) body(I2, I1);
-        else body(I2, I2);
-    } else body(I2, I0);
+        if ((wave & 3) == 0) body(I2, I1, I0);
+        else if ((wave & 3) == 1) body(I2, I1, I1);
+        else if ((wave & 3) == 2) body(I2, I1, I2);
+        else body(I2, I2, I0);
+    } else body(I2, I0, I0);
 }

@@ -21,6 +21,24 @@ _ENGINE_KW = ("n_playouts", "c_puct", "temperature", "dirichlet_ratio", "use_dir
               "backup", "use_puct", "num_probabilistic_actions")
 
 
+def _sum_progress(progs):
+    """The pools' progress dicts as one: counters summed, fault flags OR-ed, the per-pool dicts kept under "pools"."""
+    out = {}
+    for k in progs[0]:
+        vals = [p[k] for p in progs]
+        if k == "error_flags":
+            v = 0
+            for x in vals:
+                v |= int(x)
+            out[k] = v
+        elif all(isinstance(x, (int, float)) and not isinstance(x, bool) for x in vals):
+            out[k] = max(vals) if k in ("ticks", "tail_compactions") else sum(vals)
+        else:
+            out[k] = vals[0]
+    out["pools"] = list(progs)
+    return out
+
+
 class ExampleGenerator:
     def __init__(self, net, game_name, device, n_pools=1, n_processes=1, **kwargs):
         self.net2 = copy.deepcopy(kwargs["net2"]) if kwargs.get("net2") is not None else None  # examplegenerator.py:88-90
@@ -91,7 +109,7 @@ class ExampleGenerator:
                     else:
                         evaluators.append(DeviceEvaluator(copy.deepcopy(self.net), dev, dtype=self.eval_dtype))
             progs = run_selfplay_pools(engines, evaluators, n_each, use_graph=self.use_graph)
-            self.last_progress = progs[0]
+            self.last_progress = _sum_progress(progs)
             bufs = []
             for e in engines:
                 with torch.cuda.device(e.device):
@@ -100,7 +118,11 @@ class ExampleGenerator:
                 bufs.append(b.to(self.device))
             dims = (engines[0].max_plies, engines[0].max_children)
         finally:
-            for e in engines:
+            for e in engines:  # (a pool that raised leaves the others' enqueued batches behind: let every device drain first)
+                try:
+                    torch.cuda.synchronize(e.device)
+                except Exception:
+                    pass
                 e.close()
             for ev in evaluators:
                 if hasattr(ev, "close"):

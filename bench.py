@@ -47,11 +47,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "bf16": 2500.0,
                     "f16x3": 2500.0 / 3}  # fp32-grade mode: three fp16 MFMAs per product
 DTYPE_LABEL = {"f16x3": "f32-grade (f16x3: split-fp16 operands, 3 MFMAs per product, fp32 accumulate)"}
-PROFILE_SUMMARY = os.path.join("profiles", "r3_bench_default_pmc_summary.txt")
+PROFILE_SUMMARY = os.path.join("profiles", "r4_bench_default_pmc_summary.txt")
+
+
+def build_id():
+    """Identity of the kernels this run times: a hash over the engine library's SOURCES (csrc/*.hip, csrc/*.h, include/*.h).  It is
+    part of the workload key, so a committed PMC summary is quoted only when it was taken on the same kernels - a kernel change
+    without a profile refresh yields `traffic: null`, not another build's bytes."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    src = os.path.join(ROOT, "alphazero-openspiel_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:12]
 
 
 def workload_key(game, G, S, blocks, filters, net, weights, precision, overlap, tpg):
-    return "|".join(str(x) for x in (game, G, S, blocks, filters, net, weights, precision, overlap, tpg))
+    return "|".join(str(x) for x in (game, G, S, blocks, filters, net, weights, precision, overlap, tpg, "build:" + build_id()))
 
 
 def pmc_traffic(key):
@@ -557,6 +571,8 @@ def main():
                          "achieved": net_tflops, "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
                          "peak_note": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product" if args.dtype == "f16x3" else
                                        "dense MFMA peak for the dtype (MI355X_MICROARCH.md)"),
+                         # the same achieved rate against the guide's RAW peaks, whatever `peak` was derived from
+                         "frac_of_fp16_peak": net_tflops / MFMA_PEAK_TFLOPS["f16"], "x_fp32_mfma_peak": net_tflops / MFMA_PEAK_TFLOPS["f32"],
                          "frac_issued": issued_frac, "issued_mfma_per_board": issued_mfma,
                          "frac_end_to_end": e2e_tflops / peak, "end_to_end_tflops": e2e_tflops,
                          "traffic": traffic_net, "traffic_unit": "bytes/launch (PMC, %s)" % PROFILE_SUMMARY,

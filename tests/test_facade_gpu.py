@@ -166,6 +166,10 @@ def test_n_pools_as_engines_of_one_process_play_the_games_of_separate_generators
     gen = ExampleGenerator(net, "connect_four", dev, n_pools=2, pool_devices=["cuda:0", "cuda:0"], seed=11, n_slots=3, **kw)
     games = gen.generate_examples(9)   # int(9 / 2) = 4 games per pool (examplegenerator.py:149 drops the remainder)
     assert len(games) == 8
+    # the progress of BOTH pools is what callers inspect: counters summed, fault flags OR-ed, the pools' own dicts kept
+    lp = gen.last_progress
+    assert lp["games_done"] == 8 and lp["error_flags"] == 0 and len(lp["pools"]) == 2
+    assert lp["moves"] == sum(q["moves"] for q in lp["pools"]) == sum(len(g) for g in games)
     want = []
     for i in range(2):
         one = ExampleGenerator(net, "connect_four", dev, seed=11 + 7919 * i, n_slots=3, **kw)

@@ -196,21 +196,27 @@ def test_fused_f32x_forward_is_fp32_grade(tag, n):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["c4_10block", "bt6_10block", "bt5x4_3block", "bt8_2block"])
 def test_fused_f32x_outputs_do_not_depend_on_the_batch_size(tag):
-    """The fp32-grade tower has a board-per-wave kernel (az_tower_x3b_kernel, > 512 boards) and a board-per-workgroup kernel for
-    small batches (az_tower_x3c_kernel: the four waves split a board by output-channel tile): priors, value and tower output of
-    a board must be the same BITS in both - a generation's records may not depend on when its tail switches kernels.  8x8 boards
-    run az_tower_x3d_kernel (four boards packed into 16 column tiles, eight waves) at every batch size: which boards share a
-    workgroup, and ragged last workgroups, must not show either."""
+    """The fp32-grade tower runs different kernels at different batch sizes: a board per workgroup for small batches
+    (az_tower_x3c_kernel, <= 512 boards: four waves split a board by output-channel tile), a board per wave above
+    (az_tower_x3b_kernel), and - 6x6 boards above 1024, 8x8 boards always - eight (four) boards packed into whole column tiles
+    (az_tower_x3d_kernel).  Priors, value and tower output of a board must be the same BITS in all of them, whichever boards share
+    its workgroup and however ragged the last one is: a generation's records may not depend on when its tail switches kernels."""
     game, net = _nets()[tag]
-    fn = fusednet.FusedNet(net, "cuda:0", max_boards=1024, precision="f32x")
+    n_ref = 2048 if tag.startswith(("bt6", "bt8")) else 1024
+    fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_ref, precision="f32x")
     torch.manual_seed(5)
-    obs = (torch.rand(1024, 4, game.rows, game.cols, device="cuda") > 0.5).float()
+    obs = (torch.rand(n_ref, 4, game.rows, game.cols, device="cuda") > 0.5).float()
     ref_p, ref_v = [t.clone() for t in fn.forward(obs)]
     torch.cuda.synchronize()
-    ref_t = fn.read_tower(1024)
-    assert ("x3d" if tag.startswith("bt8") else "x3b") in fn.kernel_label(1024)
-    assert tag.startswith("bt8") or "x3c" in fn.kernel_label(300)
-    for n in (700, 512, 300, 256, 64, 5, 1):
+    ref_t = fn.read_tower(n_ref)
+    assert ("x3d" if tag.startswith(("bt6", "bt8")) else "x3b") in fn.kernel_label(n_ref)
+    if tag.startswith("bt6"):
+        assert "x3d" in fn.kernel_label(1500) and "x3b" in fn.kernel_label(1024) and "x3c" in fn.kernel_label(300)
+    elif not tag.startswith("bt8"):
+        assert "x3c" in fn.kernel_label(300)
+    for n in (1500, 1024, 700, 512, 300, 256, 64, 5, 1):
+        if n > n_ref:
+            continue
         p, v = fn.forward(obs[:n].contiguous())
         torch.cuda.synchronize()
         assert torch.equal(p, ref_p[:n]) and torch.equal(v, ref_v[:n]), n

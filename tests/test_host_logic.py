@@ -349,10 +349,18 @@ def test_bench_reads_hbm_traffic_only_from_a_summary_of_the_same_workload():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     key = bench.workload_key("connect_four", 4096, 400, 10, 50, "fused", "random", "f32x", 1, 16)
+    assert key.endswith("build:" + bench.build_id()) and len(bench.build_id()) == 12   # the kernels' sources are part of the key
     net, tree = bench.pmc_traffic(key)
-    assert net is not None and tree is not None
-    # the tower writes its output in hi and lo halves (2 x 4096 x 42 x 64 x 2 B = 44 MB) and the head reads it back
-    assert 60e6 < net < 200e6 and 5e6 < tree < 30e6
+    summary = open(os.path.join(ROOT, bench.PROFILE_SUMMARY)).read()
+    if ("# workload_key: " + key) in summary:   # the committed summary was taken on THIS build of the kernels: its bytes are quoted
+        assert net is not None and tree is not None
+        # the tower writes its output in hi and lo halves (2 x 4096 x 42 x 64 x 2 B = 44 MB) and the head reads it back
+        assert 60e6 < net < 200e6 and 5e6 < tree < 30e6
+    else:                                       # a kernel source changed since: null, never the other build's bytes
+        assert (net, tree) == (None, None)
+    # a summary of the same workload on OTHER kernels is not quoted either
+    stale = "|".join(key.split("|")[:-1] + ["build:000000000000"])
+    assert bench.pmc_traffic(stale) == (None, None)
     for other in (bench.workload_key("connect_four", 4096, 400, 10, 50, "fused", "random", "f16", 1, 16),
                   bench.workload_key("connect_four", 2048, 400, 10, 50, "fused", "random", "f32x", 1, 16),
                   bench.workload_key("connect_four", 4096, 400, 10, 50, "fused", "random", "f32x", 2, 16)):
