@@ -278,7 +278,7 @@ struct X3DLayout {
 static X3DLayout x3d_layout(int H, int W) {
     X3DLayout out;
     const int HW = H * W;
-    for (int v = 1; v < 3 && out.variant < 0; v++) { // (variants 0, 1 - 6x7- and 6x6-sized - are not instantiated: az_tower_x3d.hip)
+    for (int v = 0; v < AZ_X3D_VARIANTS && out.variant < 0; v++) {
         const X3DVariant V = az_x3d_variant(v);
         const int ncol = 16 * V.tiles;
         if (ncol % HW) continue;

@@ -1,33 +1,37 @@
 // az_tower_x3d.h — az_tower_x3d_kernel: the fp32-grade (split-fp16, AZ_NET_PREC_F16X3) tower on PACKED column tiles.
 // Reference computation: ResidualBlock.forward x n_blocks of Net.forward (network.py:48-64,99-104) in eval mode.
 //
-// az_tower_x3b_kernel gives every board its own column tiles: a connect_four board is 42 positions in 3 x 16 columns (12.5 % of
-// every MFMA, every B fragment and every epilogue lane is padding), a 6x6 breakthrough board 36 positions in 48 columns (25 %).
-// Here a workgroup's NB boards share their tiles: NB * H * W positions fill a whole number of tiles (connect_four: 8 boards,
-// 336 = 21 tiles; breakthrough 6x6: 8 boards, 288 = 18 tiles; 8x8: 4 boards, 256 = 16 tiles).
+// az_tower_x3b_kernel gives every board its own column tiles: a 6x6 breakthrough board is 36 positions in 3 x 16 columns - a quarter
+// of every MFMA, every B fragment and every epilogue lane is padding - and 8x8 boards run az_tower_x3_kernel, which still spends
+// a whole output-channel tile on channels 48, 49 (768 MFMAs per board and conv, 428 registers a wave).  Here a workgroup's NB boards
+// SHARE their tiles: NB * H * W positions fill a whole number of tiles (6x6: 8 boards, 288 = 18 tiles, 339 MFMAs per board and
+// conv against 441; 8x8: 4 boards, 256 = 16 tiles, 588 against 768), on x3b's scheme for channels 48, 49 (tiles T and X).
 //
 //   * WHICH positions make a tile is free - a column of an MFMA only has to be the same position in every k-step - so the host
 //     picks them for the LDS banks (az_net.hip: x3d_layout): board b's cells sit at b R + (y + 1) rs + x + 1 in a plane (halo rows
 //     and halo column(s) are zeros, so every tap shift of every position reads the conv's zero padding from memory, no masks), and
-//     R, rs are chosen so that the NB H W cells fall into the 16 residues mod 16 equally often; tile k takes the k-th position of
+//     R, rs are such that the NB H W cells fall into the 16 residues mod 16 equally often; tile k takes the k-th position of
 //     every residue, lane l15 the one of residue l15.  A ds_read_b128 of a B fragment then touches 16 different bank groups for
 //     every tap (a tap moves all 16 cells by the same amount), as with x3b's row pairs.
-//   * a workgroup is EIGHT waves, two per SIMD, every one below 256 registers (no accumulator in an AGPR: with four waves of 5-6
-//     tiles the accumulator sets alone are 290 registers - the allocator then shuttles them through the vector registers behind
-//     every MFMA of a conv's last k-step, measured 30 % of the kernel).  A wave owns two or three tiles whole (three output-channel
-//     tiles + T and X for channels 48, 49: az_tower_x3b.h); a tile left over is split by output-channel tile over four waves
-//     (mt 0, 1, 2 and T + X).  connect_four: waves 0-3 three tiles, waves 4-7 two + a quarter of tile 20 - per SIMD
-//     5 x 147 + 45 (or 12) = 780 MFMAs per conv for two boards, against 882; breakthrough 6x6: eight boards in 18 tiles, every
-//     wave two + a quarter of tile 16 or 17 (339 per board against 441); 8x8: four boards, two tiles a wave (588 against 768).
+//   * a workgroup is EIGHT waves, two per SIMD, every one within 256 registers - no accumulator in an AGPR.  (With four waves of
+//     4-6 tiles the accumulator sets alone are 220-290 registers: the allocator then copies every final value to a vector register
+//     right behind its MFMA - s_nop 7 + four v_accvgpr_read_b32 after each MFMA of a conv's last k-step, measured 30 % of that
+//     kernel.  az_tower_x3b_kernel had the same disease: pin_acc, az_net_common.h.)  A wave owns two tiles whole (three
+//     output-channel tiles + T and X); a tile left over (6x6: tiles 16, 17) is split by output-channel tile over four waves - mt 0,
+//     1, 2 and T + X, each a role compiled on its own (selecting the A fragments by a run-time branch cost 45 spilled registers).
 //   * the waves share the planes, so a conv has two more rendezvous than x3b's: the barrier of its last k-step also separates the
 //     last plane reads from the epilogue stores, and one barrier follows the epilogue.  The shifted sum of tile X goes through
 //     ONE scratch for the workgroup (a term's destination column may be another wave's), behind a chunk barrier.
-//   * weights: x3b's records in chunks of three k-steps (two 18-KiB buffers; the planes of eight boards take 96 KB, the scratch 24).
+//   * weights: x3b's records in chunks of three k-steps (two 18-KiB LDS buffers).
 //   * B fragments live in ONE register set per tile: a tile's MFMAs of a k-step run together (nine, + T and X), and its fragments of
 //     the next k-step are fetched right behind them into the same registers (waits are counted: lgkmcnt(N), N = the reads issued
-//     since); A fragments keep x3b's two-slot ring.
+//     since); A fragments of tiles 0..2 keep x3b's two-slot ring, those of T and X have one set; the per-k-step address offsets
+//     are compile-time constants selected per lane where they are used, not a table of registers.
+//   * NOT built for connect_four (8 boards = 21 tiles would take 12.5 % of the MFMAs out): 2.6 tiles a wave are 1176 accumulator
+//     registers per workgroup + fragments + tables - more than 8 x 256; with four waves of 5.25 tiles ~500 a wave, 385-600 spilled
+//     (210 with the residual stream moved to a workspace in global memory).  DESIGN_HISTORY.md, round 4.
 // Every accumulator sees the same MFMAs in the same order as in az_tower_x3b_kernel / az_tower_x3c_kernel and the epilogue is the
-// same arithmetic: a board's outputs are the same BITS in all three (tests/test_fused_net.py).
+// same arithmetic: on row-pair boards a board's outputs are the same BITS in all three (tests/test_fused_net.py).
 #pragma once
 #include "az_net_common.h"
 
@@ -70,21 +74,15 @@ template <bool IS_FIRST, int NTW, bool EXM, bool EXT> struct X3DS {
     }
 };
 
-// The three variants: which tiles wave w owns, and its share of a split tile (-1: none).
+// The variants: which tiles wave w owns, and its share of a split tile (-1: none).
 template <int V> struct X3DV;
-template <> struct X3DV<0> { // connect_four-sized: 8 boards of 42 positions in 21 tiles
-    static constexpr int NTILES = 21, PC = 480, RS = 8, R = 57;
-    __device__ static constexpr int first(int w) { return w < 4 ? 3 * w : 12 + 2 * (w - 4); }
-    __device__ static constexpr int split_tile(int w) { return w < 4 ? -1 : 20; }
-    __device__ static constexpr int split_unit(int w) { return w - 4; } // 0..2: output-channel tile; 3: T and X
-};
-template <> struct X3DV<1> { // breakthrough 6x6-sized: 8 boards of 36 positions in 18 tiles
+template <> struct X3DV<0> { // breakthrough 6x6-sized: 8 boards of 36 positions in 18 tiles
     static constexpr int NTILES = 18, PC = 480, RS = 8, R = 58;
     __device__ static constexpr int first(int w) { return 2 * w; }
     __device__ static constexpr int split_tile(int w) { return 16 + (w >> 2); }
     __device__ static constexpr int split_unit(int w) { return w & 3; }
 };
-template <> struct X3DV<2> { // 8x8: 4 boards of 64 positions in 16 tiles
+template <> struct X3DV<1> { // 8x8: 4 boards of 64 positions in 16 tiles
     static constexpr int NTILES = 16, PC = 416, RS = 9, R = 84;
     __device__ static constexpr int first(int w) { return 2 * w; }
     __device__ static constexpr int split_tile(int) { return -1; }
@@ -546,14 +544,7 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
     constexpr auto I0 = std::integral_constant<int, 0>{};
     constexpr auto I1 = std::integral_constant<int, 1>{};
     constexpr auto I2 = std::integral_constant<int, 2>{};
-    constexpr auto I3 = std::integral_constant<int, 3>{};
     if constexpr (V == 0) {
-        if (wave < 4) body(I3, I0, I0);
-        else if (wave == 4) body(I2, I1, I0);
-        else if (wave == 5) body(I2, I1, I1);
-        else if (wave == 6) body(I2, I1, I2);
-        else body(I2, I2, I0);
-    } else if constexpr (V == 1) {
         if ((wave & 3) == 0) body(I2, I1, I0);
         else if ((wave & 3) == 1) body(I2, I1, I1);
         else if ((wave & 3) == 2) body(I2, I1, I2);

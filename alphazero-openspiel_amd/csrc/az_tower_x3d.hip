@@ -15,12 +15,9 @@ template <int V> static hipError_t launch_x3d(int device, const TowerParams &tp,
     hipLaunchKernelGGL((az_tower_x3d_kernel<V>), dim3(grid), dim3(512), lds, st, tp);
     return hipGetLastError();
 }
-// variant: 0 = 8 boards in 21 tiles (6x7), 1 = 8 boards in 18 tiles (6x6), 2 = 4 boards in 16 tiles (8x8)
+// variant: 0 = 8 boards in 18 tiles (6x6), 1 = 4 boards in 16 tiles (8x8); the 6x6 roles spill ~60 registers outside the k-loop and still gain
 hipError_t az_launch_tower_x3d(int device, int variant, const TowerParams &tp, int grid, hipStream_t st) {
-    // (variant 0 - connect_four-sized: waves with three tiles need ~330 registers against the 256 that two waves per SIMD leave -
-    //  stays in the source for the day the register diet is found, uninstantiated; variant 1 - two tiles and a share of a split
-    //  tile - spills ~60 registers outside the k-loop and still gains)
+    if (variant == 0) return launch_x3d<0>(device, tp, grid, st);
     if (variant == 1) return launch_x3d<1>(device, tp, grid, st);
-    if (variant != 2) return hipErrorInvalidValue;
-    return launch_x3d<2>(device, tp, grid, st);
+    return hipErrorInvalidValue;
 }
