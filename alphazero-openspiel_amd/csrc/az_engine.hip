@@ -867,7 +867,7 @@ __device__ __forceinline__ void advance_slot_wave(const Params &p, const int g_f
     float *__restrict__ const obs_row = obs_out + (size_t)row * p.obs_elems;
     // ---- 0. everything that is addressed by the slot index alone: ONE memory round trip ------------------------
     // (the kernel is a chain of dependent reads - PMC: waves parked in s_waitcnt 63 % of their life - so its duration
-    //  is the number of round trips on the longest chain)
+    //  is the number of round trips on the longest chain; see DESIGN.md section 3 and DESIGN_HISTORY.md section 3)
     const int ph_raw = p.phase[g];
     SlotRegs sr;
     const int lf_ply_raw = p.leaf_ply[g], lf_depth_raw = p.depth[g];

@@ -126,7 +126,7 @@ typedef struct az_config {
 #define AZ_OPPONENT_RANDOM 1 /* pyspiel.make_uniform_random_bot: a uniformly random legal action */
 #define AZ_OPPONENT_UCT 2    /* open_spiel.python.algorithms.mcts.MCTSBot(game, player, uct_c, max_search_nodes,
                                 RandomRolloutEvaluator(1)) - third party, absent from the reference tree, version unpinned:
-                                restated from its published algorithm */
+                                restated from its published algorithm (DESIGN_HISTORY.md section 6) */
 #define AZ_OPPONENT_EXTERNAL 3 /* the opponent's moves come from ANOTHER engine (az_engine_exchange_moves): two AlphaZero agents with
                                   their own networks and settings - test_zero_vs_zero (game_utils.py:120-145) */
 

@@ -15,7 +15,7 @@ action differs.  On that common prefix every ply is a like-for-like comparison o
 reuse): L1 distance of the root visit vectors over S, argmax agreement.  After the first differing action the games
 are different games, so from there on only distributions are compared: game length, outcome.
 
-Tolerances asserted below are the ones DESIGN.md section 2 quotes ("within stochastic-sampling tolerance",
+Tolerances asserted below are the ones DESIGN_HISTORY.md section 2 quotes ("within stochastic-sampling tolerance",
 BASELINE.json north_star); the measured values are written to gpurun_out/precision_search_*.json.
 """
 import json
