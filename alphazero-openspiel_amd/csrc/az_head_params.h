@@ -23,10 +23,10 @@ hipError_t az_launch_tower_f16(int device, int nt, int ck, int waves, int r3, co
 hipError_t az_launch_tower_f16c(int device, int ck, const TowerParams &tp, int n_boards, int lds, hipStream_t st); // one board per workgroup (small batches); ck: k-steps per weight chunk, 8 or 4
 hipError_t az_launch_tower_x3(int device, int nt, bool rp1, int r3, const TowerParams &tp, int grid, int lds, hipStream_t st);
 hipError_t az_launch_tower_x3b(int device, const TowerParams &tp, int grid, hipStream_t st); // row-pair boards, <= 50 filters
-// packed column tiles (az_tower_x3d.h); variant: 0 = 8 boards in 18 tiles (6x6), 1 = 4 boards in 16 tiles (8x8)
+// packed column tiles (az_tower_x3d.h); variant: 0 = 8 boards in 18 tiles (6x6), 1 = 4 boards in 16 tiles (8x8), 2 = 8 boards in 21 tiles (6x7)
 hipError_t az_launch_tower_x3d(int device, int variant, const TowerParams &tp, int grid, hipStream_t st);
 struct X3DVariant { int pc, tiles, rs, R; }; // cells per plane, column tiles per workgroup, row stride, cells per board region
-constexpr int AZ_X3D_VARIANTS = 2;
-constexpr X3DVariant az_x3d_variant(int v) { return v == 0 ? X3DVariant{480, 18, 8, 58} : X3DVariant{416, 16, 9, 84}; }
+constexpr int AZ_X3D_VARIANTS = 3;
+constexpr X3DVariant az_x3d_variant(int v) { return v == 0 ? X3DVariant{480, 18, 8, 58} : v == 1 ? X3DVariant{416, 16, 9, 84} : X3DVariant{480, 21, 8, 57}; }
 hipError_t az_launch_tower_x3c(int device, int bpw, const TowerParams &tp, int n_boards, hipStream_t st); // the same, a board per four waves, bpw boards per workgroup
 hipError_t az_launch_head(int device, bool x3, const HeadParams &hp, int n_boards, int lds_head, float *logits, hipStream_t st);

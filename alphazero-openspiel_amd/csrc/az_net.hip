@@ -190,7 +190,20 @@ static X3Stream x3d_stream_layout() {
         L.ks0[part] = X3D::part_ks0(part), L.ks1[part] = X3D::part_ks0(part) + X3D::part_len(part), L.off[part] = X3D::part_off(part);
     return L;
 }
-static void build_x3_stream(const X3Stream &L, const uint16_t *hi, const uint16_t *lo, int n_convs, std::vector<unsigned char> &dev) {
+// The hi halves go into these streams x 2048 (X3_WSCALE; the lo halves carry that factor in the interchange format already): with
+// the activations' lo half unscaled between convs, every product of a split-fp16 multiply is then 2048 x its share and ONE
+// accumulator takes all three (az_net_common.h: split_pair_planes).  Exact (a power of two) unless |w| >= 32: -> false.
+static bool build_x3_stream(const X3Stream &L, const uint16_t *hi_abi, const uint16_t *lo, int n_convs, std::vector<unsigned char> &dev) {
+    std::vector<uint16_t> hi_scaled((size_t)n_convs * AZ_NET_KSTEPS * 2048);
+    for (size_t i = 0; i < hi_scaled.size(); i++) {
+        _Float16 h;
+        memcpy(&h, &hi_abi[i], 2);
+        const float f = (float)h * 2048.0f;
+        if (!(f > -65520.0f && f < 65520.0f)) return false;
+        h = (_Float16)f;
+        memcpy(&hi_scaled[i], &h, 2);
+    }
+    const uint16_t *hi = hi_scaled.data();
     // (+ two convs of zero padding: the kernels' fetch of "chunk + 2" is unconditional)
     dev.assign(L.c0_b + (size_t)(n_convs - 1) * L.conv_b + 2 * L.conv_b, 0);
     constexpr int FR = X3B::FR, REC2 = X3B::REC2;
@@ -264,6 +277,7 @@ static void build_x3_stream(const X3Stream &L, const uint16_t *hi, const uint16_
             }
         }
     }
+    return true;
 }
 
 // Column layout of az_tower_x3d_kernel (az_tower_x3d.h) for an H x W board: boards per workgroup, row stride, cells per board
@@ -463,14 +477,20 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
             if (L.variant >= 0) {
                 n->x3d = L.variant, n->xd_nb = L.nb, n->xd_R = L.R, n->xd_rs = L.rs;
                 std::vector<unsigned char> sd;
-                build_x3_stream(x3d_stream_layout(), d.conv_w, d.conv_w_lo, n_convs, sd);
+                if (!build_x3_stream(x3d_stream_layout(), d.conv_w, d.conv_w_lo, n_convs, sd)) {
+                    g_net_err = "AZ_NET_PREC_F16X3: a conv weight of magnitude >= 32 (the device copy holds the weights x 2048 in fp16)";
+                    rc = AZ_E_INVALID;
+                }
                 up((void **)&n->conv_w_d, sd.data(), sd.size());
                 up((void **)&n->xd_pos, L.pos.data(), L.pos.size() * 2);
                 up((void **)&n->xd_sdst, L.sdst.data(), L.sdst.size() * 2);
             }
         }
         if (n->x3b) {
-            build_x3_stream(x3b_stream_layout(), d.conv_w, d.conv_w_lo, n_convs, dev);
+            if (!build_x3_stream(x3b_stream_layout(), d.conv_w, d.conv_w_lo, n_convs, dev)) {
+                g_net_err = "AZ_NET_PREC_F16X3: a conv weight of magnitude >= 32 (the device copy holds the weights x 2048 in fp16)";
+                rc = AZ_E_INVALID;
+            }
             up((void **)&n->conv_w, dev.data(), dev.size());
         } else {
         build_records((const unsigned char *)d.conv_w, hi);

@@ -109,6 +109,27 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, uns
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(lo) : "v"(hi), "v"(m), "v"(t0));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(m), "v"(t1));
 }
+// BETWEEN the convs of a tower the lo half is kept UNSCALED: lo0 = fp16(x - hi) (one v_fma_mix per value: fma(hi, -1, x), exact
+// before the conversion).  The weights carry the factor instead - both halves of a weight are stored x 2048 (hi' = 2048 fp16(w),
+// lo = 2048 (w - fp16(w)): az_net.hip) - so that the three products of a split-fp16 multiply, hi' bh + hi' bl0 + lo bh, all come
+// out 2048 times the true product and go into ONE fp32 accumulator (no second accumulator set for the cross terms: a third of the
+// accumulator registers).  An unscaled lo is a subnormal fp16 for |x| < 0.125: its absolute error is then 2^-25 at most, which a
+// 450-term conv with |w| ~ 0.05 turns into ~2e-8 of its output - below fp32's own rounding of the sum.
+__device__ __forceinline__ void split_pair_planes(float x0, float x1, unsigned &hi, unsigned &lo0) {
+    const float m = -1.0f;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(lo0) : "v"(hi), "v"(m), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo0) : "v"(hi), "v"(m), "v"(x1));
+}
+__device__ __forceinline__ void split4_planes(const f32x4 &v, half4 &hi, half4 &lo0) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned h0, h1, l0, l1;
+    split_pair_planes(v[0], v[1], h0, l0);
+    split_pair_planes(v[2], v[3], h1, l1);
+    hi = __builtin_bit_cast(half4, (u32x2){h0, h1});
+    lo0 = __builtin_bit_cast(half4, (u32x2){l0, l1});
+}
+#define X3_WSCALE 2048.0f // the factor the fp32-grade towers' weights (and therefore their accumulators) carry
 // four values at once (the fp32-grade towers' epilogues)
 __device__ __forceinline__ void split4_f16x3(const f32x4 &v, half4 &hi, half4 &lo) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));

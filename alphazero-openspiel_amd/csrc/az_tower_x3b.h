@@ -22,6 +22,9 @@
 //     times: with the hi and lo weights on different ROWS one MFMA yields hi*hi and lo*hi together.
 // MFMAs per column tile and conv: 15 x 9 (tiles 0..2, three per product) + 2 x (2 T + 3 X) + 2 T = 147 against 180: -18 %.
 //
+// Since round 4 a tile has ONE accumulator (az_net_common.h: split_pair_planes): the device copy of the weights carries 2048 in both
+// halves and the planes keep the lo half unscaled, so the three MFMAs of a product add into the same registers; an accumulator
+// holds 2048 x the conv, the epilogue scales it back (exactly).
 // Everything else is az_tower_x3_kernel's: one workgroup = 4 waves (one per SIMD), one board per wave, hi and lo
 // activation planes, fp32 residual stream in registers, fp32 epilogues that split their result into (hi, lo) again.
 // The compact plane of channels 48, 49 takes its real 4 bytes per cell (the scratch S lives in what that frees).
@@ -84,8 +87,8 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
     // x -> (hi, lo): hi = fp16(x), lo = fp16((x - hi) * 2048)
     auto split4 = [&](const f32x4 &v, half4 &hi, half4 &lo) { split4_f16x3(v, hi, lo); }; // (five instructions per pair: az_net_common.h)
 
-    f32x4 acc[4][NT], acc2[4][NT], xres[4][NT]; // [3]: tile T
-    f32x4 accxh[NT], accxl[NT];                 // tile X
+    f32x4 acc[4][NT], xres[4][NT]; // [3]: tile T.  The accumulators hold 2048 x the conv (X3_WSCALE)
+    f32x4 accx[NT];                // tile X
     { // prologue: a = lrelu(bn1(x0)) -> octet 0 (hi, lo); block-1 skip conv3(x0) in fp32 -> residual stream
         f32x4 sw[4][4];
 #pragma unroll
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
 #pragma unroll
                     for (int c = 0; c < 4; c++) a[c] = c < p.cin ? lrelu(p.in_scale[c] * v[c] + p.in_shift[c]) : 0.f;
                     half4 hi, lo;
-                    split4(a, hi, lo);
+                    split4_planes(a, hi, lo);
                     *(half4 *)(lds + pos_addr[nt]) = hi;
                     *(half4 *)(lds + pos_addr[nt] + LO_OFF) = lo;
                 }
@@ -118,12 +121,10 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
                     x[r] = sw[mt][r][0] * v[0] + sw[mt][r][1] * v[1] + sw[mt][r][2] * v[2] + sw[mt][r][3] * v[3];
                 xres[mt][nt] = x;
                 // tile T: only channels 48, 49 (lanes q == 0, rows 0, 1) carry a bias; its other rows are lo / centre-tap rows
-                acc[mt][nt] = (mt < 3 || q == 0) ? *(const f32x4 *)(p.epi + 16 * mt + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[mt][nt] = (mt < 3 || q == 0) ? *(const f32x4 *)(p.epi + 16 * mt + 4 * q) * X3_WSCALE : (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (mt == 3) acc[mt][nt][2] = acc[mt][nt][3] = 0.f;
-                acc2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            accxh[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            accxl[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            accx[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
 
@@ -223,9 +224,9 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
             if constexpr (IS_FIRST) return;
             if constexpr (ks == 8 && j < 9 * NT) { // 9 slots per column tile: 4 combine, 2 centre, 3 stores
                 constexpr int nt = j / 9, i = j % 9;
-                if constexpr (i < 4) xv[i] = __builtin_fmaf(accxl[nt][i], INV_SPLIT, accxh[nt][i]); // (= accxh + accxl / 2048, bit for bit: the scaling is exact)
+                if constexpr (i < 4) xv[i] = accx[nt][i] * INV_SPLIT;
                 else if constexpr (i < 6) // (lanes q == 1 hold rows 4..7 of tile T: hi c0, hi c1, lo c0, lo c1 of the centre tap)
-                    cv[i - 4] = __builtin_fmaf(acc[3][nt][i - 2] + acc2[3][nt][i - 4], INV_SPLIT, acc[3][nt][i - 4]);
+                    cv[i - 4] = (acc[3][nt][i - 4] + acc[3][nt][i - 2]) * INV_SPLIT;
                 else if constexpr (i == 6) lds_write64(lds_base + sdst[nt][0], (f32x2){xv[0], xv[1]});
                 else if constexpr (i == 7) lds_write64(lds_base + sdst[nt][1], (f32x2){xv[2], xv[3]});
                 else lds_write64(lds_base + scen[nt], cv);
@@ -271,8 +272,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!IS_FIRST && ks == 8) // (tile X is final: keep it in its AGPRs until the scratch path reads it, below)
                 static_for<NT>([&](auto nt_c) {
-                    pin_acc(accxh[decltype(nt_c)::value]);
-                    pin_acc(accxl[decltype(nt_c)::value]);
+                    pin_acc(accx[decltype(nt_c)::value]);
                 });
             if constexpr (last_of_conv)
                 static_for<4>([&](auto mt_c) {
@@ -315,26 +315,28 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
                         return __builtin_bit_cast(half8, u);
                     } else return bl[cur][nt];
                 };
-                if constexpr (j < 9 * NT) { // tiles 0..2: pass 0 hi*hi -> acc, pass 1 hi*lo, pass 2 lo*hi -> acc2 (scaled by 2048)
+                // ONE accumulator per tile: the weights carry 2048 in both halves and the activations' lo half is unscaled, so hi'*hi,
+                // hi'*lo0 and lo*hi are all 2048 x their share of the product (az_net_common.h: split_pair_planes).  Order per accumulator
+                // and k-step - hi'*hi, hi'*lo0, lo*hi - is the same in az_tower_x3c_kernel and az_tower_x3d_kernel: same bits.
+                if constexpr (j < 9 * NT) { // tiles 0..2, pass-major over the (tile, column tile) pairs
                     constexpr int pass = j / (3 * NT), nt = (j % (3 * NT)) / 3, mt = j % 3;
                     constexpr auto ntc = std::integral_constant<int, nt>{};
                     const half8 a_hi = ks == 0 ? ah0[mt] : ah[cur][mt], a_lo = ks == 0 ? al0[mt] : al[cur][mt];
                     if constexpr (pass == 0) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi(ntc), acc[mt][nt], 0, 0, 0);
-                    else if constexpr (pass == 1) // (the conv's first product into acc2 starts from a literal 0: no re-zeroing in the epilogue)
-                        acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo(ntc), ks == 0 ? zero4 : acc2[mt][nt], 0, 0, 0);
-                    else acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi(ntc), acc2[mt][nt], 0, 0, 0);
-                } else if constexpr (T_ON && j < 11 * NT) { // tile T: x B_hi -> acc[3] (hi rows: hi*hi, lo rows: lo*hi), x B_lo -> acc2[3] (hi rows: hi*lo)
+                    else if constexpr (pass == 1) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo(ntc), acc[mt][nt], 0, 0, 0);
+                    else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi(ntc), acc[mt][nt], 0, 0, 0);
+                } else if constexpr (T_ON && j < 11 * NT) { // tile T (hi rows and lo rows in one fragment): x B_hi, then x B_lo0
                     constexpr int jj = j - 9 * NT, nt = jj % NT;
                     constexpr auto ntc = std::integral_constant<int, nt>{};
                     const half8 a_t = ks == 0 ? at0 : at[cur];
                     if constexpr (jj < NT) acc[3][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_t, b_hi(ntc), acc[3][nt], 0, 0, 0);
-                    else acc2[3][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_t, b_lo(ntc), ks == (IS_FIRST ? 0 : 6) ? zero4 : acc2[3][nt], 0, 0, 0);
-                } else { // tile X: hi*hi -> accxh; hi*lo, lo*hi -> accxl
+                    else acc[3][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_t, b_lo(ntc), acc[3][nt], 0, 0, 0);
+                } else { // tile X: hi'*hi (from a literal 0 at k-step 6), hi'*lo0, lo*hi
                     constexpr int jj = j - 11 * NT, nt = jj % NT;
                     constexpr auto ntc = std::integral_constant<int, nt>{};
-                    if constexpr (jj < NT) accxh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_hi(ntc), ks == 6 ? zero4 : accxh[nt], 0, 0, 0);
-                    else if constexpr (jj < 2 * NT) accxl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_lo(ntc), ks == 6 ? zero4 : accxl[nt], 0, 0, 0);
-                    else accxl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axl[cur], b_hi(ntc), accxl[nt], 0, 0, 0);
+                    if constexpr (jj < NT) accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_hi(ntc), ks == 6 ? zero4 : accx[nt], 0, 0, 0);
+                    else if constexpr (jj < 2 * NT) accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_lo(ntc), accx[nt], 0, 0, 0);
+                    else accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axl[cur], b_hi(ntc), accx[nt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -368,7 +370,6 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
                 pin_acc(acc[mt][nt]);
-                pin_acc(acc2[mt][nt]);
             }
         // ---- epilogue, in fp32; the result is split into (hi, lo) again ------------------------------------------
         auto epilogue = [&](auto kind) {
@@ -382,17 +383,16 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
                 for (int nt = 0; nt < NT; nt++) {
                     f32x4 v;
                     if (mt < 3) {
-                        v = comb_f16x3(acc[mt][nt], acc2[mt][nt]);
-                        acc[mt][nt] = next_bias;
+                        v = acc[mt][nt] * INV_SPLIT;
+                        acc[mt][nt] = next_bias * X3_WSCALE;
                     } else { // tile T, lanes q == 0: rows hi 48, hi 49, lo 48, lo 49 of the gather k-step (+ bias), plus the tap planes
-                        v = (f32x4){__builtin_fmaf(acc[3][nt][2] + acc2[3][nt][0], INV_SPLIT, acc[3][nt][0]),
-                                    __builtin_fmaf(acc[3][nt][3] + acc2[3][nt][1], INV_SPLIT, acc[3][nt][1]), 0.f, 0.f};
+                        v = (f32x4){(acc[3][nt][0] + acc[3][nt][2]) * INV_SPLIT, (acc[3][nt][1] + acc[3][nt][3]) * INV_SPLIT, 0.f, 0.f};
                         if constexpr (!IS_FIRST) {
                             v[0] += s49[nt][0];
                             v[1] += s49[nt][1];
                         }
                         if (q != 0) v = (f32x4){0.f, 0.f, 0.f, 0.f}; // (rows 4..15: centre-tap rows / unused)
-                        acc[3][nt] = q == 0 ? (f32x4){next_bias[0], next_bias[1], 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        acc[3][nt] = q == 0 ? (f32x4){next_bias[0] * X3_WSCALE, next_bias[1] * X3_WSCALE, 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
                     f32x4 o;
                     if (KIND == 0) {
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
                         o = __builtin_elementwise_max(a, a * 0.01f);
                     }
                     half4 hi, lo;
-                    split4(o, hi, lo);
+                    split4_planes(o, hi, lo); // (between convs the lo half is unscaled; the tower OUTPUT above keeps lo x 2048: the head's format)
                     if (mt == 3) { // channels 48, 49 -> the compact planes
                         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                         const bool live = q == 0 && grow[nt] >= 0;

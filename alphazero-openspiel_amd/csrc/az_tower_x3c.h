@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
         constexpr int ROLE = decltype(role_c)::value;
         constexpr bool TX = ROLE == 3;
         constexpr int mt = ROLE; // (tile T keeps index 3 in the parameter tables)
-        f32x4 acc[NT], acc2[NT], xres[NT]; // this wave's tile (ROLE 3: tile T)
-        f32x4 accxh[NT], accxl[NT];        // ROLE 3: tile X
+        f32x4 acc[NT], xres[NT]; // this wave's tile (ROLE 3: tile T); ONE accumulator, 2048 x the conv (az_tower_x3b.h)
+        f32x4 accx[NT];          // ROLE 3: tile X
         { // prologue: wave 0 writes a = lrelu(bn1(x0)) -> octet 0 (hi, lo); every wave takes its tile's share of the block-1 skip conv
             f32x4 sw[4];
 #pragma unroll
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
 #pragma unroll
                         for (int c = 0; c < 4; c++) a[c] = c < p.cin ? lrelu(p.in_scale[c] * v[c] + p.in_shift[c]) : 0.f;
                         half4 hi, lo;
-                        split4(a, hi, lo);
+                        split4_planes(a, hi, lo);
                         *(half4 *)(lds + pos_addr[nt]) = hi;
                         *(half4 *)(lds + pos_addr[nt] + LO_OFF) = lo;
                     }
@@ -124,11 +124,9 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
 #pragma unroll
                 for (int r = 0; r < 4; r++) x[r] = sw[r][0] * v[0] + sw[r][1] * v[1] + sw[r][2] * v[2] + sw[r][3] * v[3];
                 xres[nt] = x;
-                acc[nt] = (!TX || q == 0) ? *(const f32x4 *)(p.epi + 16 * mt + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[nt] = (!TX || q == 0) ? *(const f32x4 *)(p.epi + 16 * mt + 4 * q) * X3_WSCALE : (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (TX) acc[nt][2] = acc[nt][3] = 0.f;
-                acc2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                accxh[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                accxl[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                accx[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
         // scratch addresses (ROLE 3; az_tower_x3b.h)
@@ -281,25 +279,25 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
                             return __builtin_bit_cast(half8, u);
                         } else return bl[cur][nt];
                     };
-                    if constexpr (!TX) { // pass 0 hi*hi -> acc, pass 1 hi*lo, pass 2 lo*hi -> acc2 (scaled by 2048)
+                    if constexpr (!TX) { // one accumulator: hi'*hi, hi'*lo0, lo*hi (the order of az_tower_x3b_kernel per accumulator and k-step)
                         constexpr int pass = j / NT, nt = j % NT;
                         constexpr auto ntc = std::integral_constant<int, nt>{};
                         const half8 a_hi = ks == 0 ? ah0 : ah[cur], a_lo = ks == 0 ? al0 : al[cur];
                         if constexpr (pass == 0) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi(ntc), acc[nt], 0, 0, 0);
-                        else if constexpr (pass == 1) acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo(ntc), ks == 0 ? zero4 : acc2[nt], 0, 0, 0);
-                        else acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi(ntc), acc2[nt], 0, 0, 0);
+                        else if constexpr (pass == 1) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo(ntc), acc[nt], 0, 0, 0);
+                        else acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi(ntc), acc[nt], 0, 0, 0);
                     } else if constexpr (T_ON && j < 2 * NT) {
                         constexpr int nt = j % NT;
                         constexpr auto ntc = std::integral_constant<int, nt>{};
                         const half8 a_t = ks == 0 ? at0 : at[cur];
                         if constexpr (j < NT) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_t, b_hi(ntc), acc[nt], 0, 0, 0);
-                        else acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_t, b_lo(ntc), ks == (IS_FIRST ? 0 : 6) ? zero4 : acc2[nt], 0, 0, 0);
+                        else acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_t, b_lo(ntc), acc[nt], 0, 0, 0);
                     } else {
                         constexpr int jj = j - 2 * NT, nt = jj % NT;
                         constexpr auto ntc = std::integral_constant<int, nt>{};
-                        if constexpr (jj < NT) accxh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_hi(ntc), ks == 6 ? zero4 : accxh[nt], 0, 0, 0);
-                        else if constexpr (jj < 2 * NT) accxl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_lo(ntc), ks == 6 ? zero4 : accxl[nt], 0, 0, 0);
-                        else accxl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axl[cur], b_hi(ntc), accxl[nt], 0, 0, 0);
+                        if constexpr (jj < NT) accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_hi(ntc), ks == 6 ? zero4 : accx[nt], 0, 0, 0);
+                        else if constexpr (jj < 2 * NT) accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh[cur], b_lo(ntc), accx[nt], 0, 0, 0);
+                        else accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axl[cur], b_hi(ntc), accx[nt], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -311,10 +309,10 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
                     for (int nt = 0; nt < NT; nt++) {
                         f32x4 xv;
 #pragma unroll
-                        for (int i = 0; i < 4; i++) xv[i] = __builtin_fmaf(accxl[nt][i], INV_SPLIT, accxh[nt][i]);
+                        for (int i = 0; i < 4; i++) xv[i] = accx[nt][i] * INV_SPLIT;
                         f32x2 cv;
 #pragma unroll
-                        for (int i = 0; i < 2; i++) cv[i] = __builtin_fmaf(acc[nt][i + 2] + acc2[nt][i], INV_SPLIT, acc[nt][i]);
+                        for (int i = 0; i < 2; i++) cv[i] = (acc[nt][i] + acc[nt][i + 2]) * INV_SPLIT;
                         lds_write64(lds_base + sdst[nt][0], (f32x2){xv[0], xv[1]});
                         lds_write64(lds_base + sdst[nt][1], (f32x2){xv[2], xv[3]});
                         lds_write64(lds_base + scen[nt], cv);
@@ -356,16 +354,16 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
                 for (int nt = 0; nt < NT; nt++) {
                     f32x4 v;
                     if constexpr (!TX) {
-                        v = comb_f16x3(acc[nt], acc2[nt]);
-                        acc[nt] = next_bias;
+                        v = acc[nt] * INV_SPLIT;
+                        acc[nt] = next_bias * X3_WSCALE;
                     } else {
-                        v = (f32x4){__builtin_fmaf(acc[nt][2] + acc2[nt][0], INV_SPLIT, acc[nt][0]), __builtin_fmaf(acc[nt][3] + acc2[nt][1], INV_SPLIT, acc[nt][1]), 0.f, 0.f};
+                        v = (f32x4){(acc[nt][0] + acc[nt][2]) * INV_SPLIT, (acc[nt][1] + acc[nt][3]) * INV_SPLIT, 0.f, 0.f};
                         if constexpr (!IS_FIRST) {
                             v[0] += s49[nt][0];
                             v[1] += s49[nt][1];
                         }
                         if (q != 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        acc[nt] = q == 0 ? (f32x4){next_bias[0], next_bias[1], 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        acc[nt] = q == 0 ? (f32x4){next_bias[0] * X3_WSCALE, next_bias[1] * X3_WSCALE, 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
                     f32x4 o;
                     if (KIND == 0) {
@@ -388,7 +386,8 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
                         }
                     }
                     half4 hi, lo;
-                    split4(o, hi, lo);
+                    if (KIND == 2) split4(o, hi, lo); // (the tower OUTPUT in the planes, for the fused head: its format, lo x 2048)
+                    else split4_planes(o, hi, lo);    // between convs the lo half is unscaled (az_net_common.h)
                     if constexpr (TX) {
                         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                         const bool live = q == 0 && grow[nt] >= 0;

@@ -88,6 +88,11 @@ template <> struct X3DV<1> { // 8x8: 4 boards of 64 positions in 16 tiles
     __device__ static constexpr int split_tile(int) { return -1; }
     __device__ static constexpr int split_unit(int) { return 0; }
 };
+template <> struct X3DV<2> { // connect_four-sized: 8 boards of 42 positions in 21 tiles - waves 0-3 three tiles, waves 4-7 two and a quarter of tile 20
+    static constexpr int NTILES = 21, PC = 480, RS = 8, R = 57;
+    __device__ static constexpr int first(int w) { return w < 4 ? 3 * w : 12 + 2 * (w - 4); }
+    __device__ static constexpr int split_tile(int w) { return w < 4 ? -1 : 20; }
+};
 template <int V> struct X3DG {
     static constexpr int PC = X3DV<V>::PC, NCOL = 16 * X3DV<V>::NTILES;
     static constexpr int PLANE_B = PC * OCT_B, LO_OFF = 6 * PLANE_B + PC * 4; // hi: 6 octet planes + the compact plane of channels 48, 49
@@ -129,7 +134,6 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
     auto sel4 = [](int qq, int c0, int c1, int c2, int c3) { return qq == 0 ? c0 : qq == 1 ? c1 : qq == 2 ? c2 : c3; };
 
     auto split4 = [&](const f32x4 &v, half4 &hi, half4 &lo) { split4_f16x3(v, hi, lo); }; // x -> (hi, lo): az_net_common.h
-    auto comb4 = [&](const f32x4 &a, const f32x4 &a2) { return comb_f16x3(a, a2); };      // a + a2 / 2048
     __syncthreads(); // the zeroes are down before the input planes are written
 
     // ---- weight stream: chunk -> buffer chunk & 1 by LDS-DMA (global_load_lds, one KiB per wave-instruction)
@@ -177,10 +181,11 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
         // the lane's cell in the compact plane of channels 48, 49 (4 bytes per cell), from its octet-plane address (16 bytes per cell);
         // opaque: derived where it is used, not carried in a register per tile
         auto p6_of = [&](int nt) { return ((opaque((int)baseL[nt]) - (int)lds_base - G::OFF_ACT) >> 2) + (int)lds_base + G::OFF_ACT + 6 * plane_b; };
-        f32x4 acc[3][NTW], acc2[3][NTW], xres[3][NTW];    // output-channel tiles 0..2 of the wave's own column tiles
-        f32x4 accT[NTT], acc2T[NTT], xresT[NTT];           // tile T
-        f32x4 accxh[NTT], accxl[NTT];                      // tile X
-        f32x4 acce, acc2e, xrese;                          // EXM: tile mt = wave of the extra column tile
+        // ONE accumulator per tile, holding 2048 x the conv (az_tower_x3b.h; az_net_common.h: split_pair_planes)
+        f32x4 acc[3][NTW], xres[3][NTW]; // output-channel tiles 0..2 of the wave's own column tiles
+        f32x4 accT[NTT], xresT[NTT];     // tile T
+        f32x4 accx[NTT];                 // tile X
+        f32x4 acce, xrese;               // EXM: output-channel tile emt of the split column tile
         { // prologue: a = lrelu(bn1(x0)) -> octet 0 (hi, lo); block-1 skip conv3(x0) in fp32 -> residual stream
             f32x4 sw[4][4];
 #pragma unroll
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                 return x;
             };
             auto bias_t = [&]() { // tile T: only channels 48, 49 (lanes q == 0, rows 0, 1) carry a bias; its other rows are lo / centre-tap rows
-                f32x4 b = q == 0 ? *(const f32x4 *)(p.epi + 48) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 b = q == 0 ? *(const f32x4 *)(p.epi + 48) * X3_WSCALE : (f32x4){0.f, 0.f, 0.f, 0.f};
                 b[2] = b[3] = 0.f;
                 return b;
             };
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
 #pragma unroll
                         for (int c = 0; c < 4; c++) a[c] = c < p.cin ? lrelu(p.in_scale[c] * v[c] + p.in_shift[c]) : 0.f;
                         half4 hi, lo;
-                        split4(a, hi, lo);
+                        split4_planes(a, hi, lo);
                         *(half4 *)(lds + (baseL[nt] - lds_base)) = hi;
                         *(half4 *)(lds + (baseL[nt] - lds_base) + LO_OFF) = lo;
                     }
@@ -223,18 +228,16 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
 #pragma unroll
                     for (int mt = 0; mt < 3; mt++) {
                         xres[mt][nt] = skip(sw[mt], v);
-                        acc[mt][nt] = *(const f32x4 *)(p.epi + 16 * mt + 4 * q);
-                        acc2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        acc[mt][nt] = *(const f32x4 *)(p.epi + 16 * mt + 4 * q) * X3_WSCALE;
                     }
                 }
                 if (nt < NTT) {
                     xresT[nt] = skip(sw[3], v);
                     accT[nt] = bias_t();
-                    acc2T[nt] = accxh[nt] = accxl[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    accx[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 } else if (EXM) {
                     xrese = skip(swe, v);
-                    acce = *(const f32x4 *)(p.epi + 16 * emt + 4 * q);
-                    acc2e = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    acce = *(const f32x4 *)(p.epi + 16 * emt + 4 * q) * X3_WSCALE;
                 }
             }
         }
@@ -338,10 +341,10 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                 if constexpr (S_STORE) {
 #pragma unroll
                     for (int nt = 0; nt < NTT; nt++) {
-                        const f32x4 xv = comb4(accxh[nt], accxl[nt]);
+                        const f32x4 xv = accx[nt] * INV_SPLIT;
                         f32x2 cv; // (lanes q == 1 hold rows 4..7 of tile T: hi c0, hi c1, lo c0, lo c1 of the centre tap)
 #pragma unroll
-                        for (int i = 0; i < 2; i++) cv[i] = __builtin_fmaf(accT[nt][i + 2] + acc2T[nt][i], INV_SPLIT, accT[nt][i]);
+                        for (int i = 0; i < 2; i++) cv[i] = (accT[nt][i] + accT[nt][i + 2]) * INV_SPLIT;
                         lds_write64(lds_base + sdst[nt][0], (f32x2){xv[0], xv[1]});
                         lds_write64(lds_base + sdst[nt][1], (f32x2){xv[2], xv[3]});
                         lds_write64(lds_base + scen[nt], cv);
@@ -403,29 +406,27 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                             }
                         }
                         if constexpr (j < n_main) {
-                            // order within a tile: hi*lo -> acc2, hi*hi -> acc, lo*hi -> acc2 (per accumulator the order of x3b: hi*lo before lo*hi)
+                            // per accumulator and k-step: hi'*hi, hi'*lo0, lo*hi (the order of az_tower_x3b_kernel: same bits); within a tile
+                            // pass-major, so that an accumulator's three MFMAs are three slots apart
                             constexpr int pass = OWN ? j / 3 : j, mt = OWN ? j % 3 : 0;
                             if constexpr (OWN) {
                                 const half8 a_hi = ah[cur][mt], a_lo = al[cur][mt];
-                                if constexpr (pass == 0) acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, ks == 0 ? zero4 : acc2[mt][nt], 0, 0, 0);
-                                else if constexpr (pass == 1) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acc[mt][nt], 0, 0, 0);
-                                else acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, acc2[mt][nt], 0, 0, 0);
+                                if constexpr (pass == 0) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acc[mt][nt], 0, 0, 0);
+                                else if constexpr (pass == 1) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, acc[mt][nt], 0, 0, 0);
+                                else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, acc[mt][nt], 0, 0, 0);
                             } else { // the split tile's output-channel tile mt = emt
-                                auto one = [&](const half8 &a_hi, const half8 &a_lo) {
-                                    if constexpr (pass == 0) acc2e = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, ks == 0 ? zero4 : acc2e, 0, 0, 0);
-                                    else if constexpr (pass == 1) acce = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acce, 0, 0, 0);
-                                    else acc2e = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, acc2e, 0, 0, 0);
-                                };
-                                one(ah[cur][emt], al[cur][emt]);
+                                if constexpr (pass == 0) acce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][emt], b_hi, acce, 0, 0, 0);
+                                else if constexpr (pass == 1) acce = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][emt], b_lo, acce, 0, 0, 0);
+                                else acce = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][emt], b_hi, acce, 0, 0, 0);
                             }
-                        } else if constexpr (j < n_main + n_t) { // tile T: x B_hi -> accT (hi rows: hi*hi, lo rows: lo*hi), x B_lo -> acc2T (hi rows: hi*lo)
+                        } else if constexpr (j < n_main + n_t) { // tile T (hi rows and lo rows in one fragment): x B_hi, then x B_lo0
                             if constexpr (j == n_main) accT[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at, b_hi, accT[nt], 0, 0, 0);
-                            else acc2T[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at, b_lo, ks == (IS_FIRST ? 0 : 6) ? zero4 : acc2T[nt], 0, 0, 0);
-                        } else { // tile X: hi*hi -> accxh; hi*lo, lo*hi -> accxl
+                            else accT[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at, b_lo, accT[nt], 0, 0, 0);
+                        } else { // tile X: hi'*hi (from a literal 0 at k-step 6), hi'*lo0, lo*hi
                             constexpr int jj = j - n_main - n_t;
-                            if constexpr (jj == 0) accxh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh, b_hi, ks == 6 ? zero4 : accxh[nt], 0, 0, 0);
-                            else if constexpr (jj == 1) accxl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh, b_lo, ks == 6 ? zero4 : accxl[nt], 0, 0, 0);
-                            else accxl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axl, b_hi, accxl[nt], 0, 0, 0);
+                            if constexpr (jj == 0) accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh, b_hi, ks == 6 ? zero4 : accx[nt], 0, 0, 0);
+                            else if constexpr (jj == 1) accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axh, b_lo, accx[nt], 0, 0, 0);
+                            else accx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axl, b_hi, accx[nt], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     });
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
             });
             // ---- epilogue, in fp32; the result is split into (hi, lo) again (az_tower_x3b.h: the same arithmetic) -------------
             const unsigned ep_base = lds_base + X3D::OFF_EPI + (conv & 1) * 1024 + q * 16;
-            auto unit = [&](auto kind, auto tt_c, f32x4 &a, f32x4 &a2, f32x4 &xr, const f32x2 &s, const int mt, const int nt,
+            auto unit = [&](auto kind, auto tt_c, f32x4 &a, f32x4 &xr, const f32x2 &s, const int mt, const int nt,
                             const f32x4 &sc, const f32x4 &sh, const f32x4 &next_bias) {
                 constexpr int KIND = decltype(kind)::value; // 0: conv1, 1: conv2 (not last), 2: last conv
                 constexpr bool TT = decltype(tt_c)::value;  // tile T
@@ -455,16 +456,16 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                 const int woff = (2 * mt + (q >> 1)) * plane_b + (q & 1) * 8;
                 f32x4 v;
                 if constexpr (!TT) {
-                    v = comb4(a, a2);
-                    a = next_bias;
+                    v = a * INV_SPLIT;
+                    a = next_bias * X3_WSCALE;
                 } else { // lanes q == 0: rows hi 48, hi 49, lo 48, lo 49 of the gather k-step (+ bias), plus the tap planes
-                    v = (f32x4){__builtin_fmaf(a[2] + a2[0], INV_SPLIT, a[0]), __builtin_fmaf(a[3] + a2[1], INV_SPLIT, a[1]), 0.f, 0.f};
+                    v = (f32x4){(a[0] + a[2]) * INV_SPLIT, (a[1] + a[3]) * INV_SPLIT, 0.f, 0.f};
                     if constexpr (!IS_FIRST) {
                         v[0] += s[0];
                         v[1] += s[1];
                     }
                     if (q != 0) v = (f32x4){0.f, 0.f, 0.f, 0.f}; // (rows 4..15: centre-tap rows / unused)
-                    a = q == 0 ? (f32x4){next_bias[0], next_bias[1], 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    a = q == 0 ? (f32x4){next_bias[0] * X3_WSCALE, next_bias[1] * X3_WSCALE, 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 f32x4 o;
                 if constexpr (KIND == 0) {
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                     o = __builtin_elementwise_max(t, t * 0.01f);
                 }
                 half4 hi, lo;
-                split4(o, hi, lo);
+                split4_planes(o, hi, lo); // (between convs the lo half is unscaled; the tower OUTPUT above keeps lo x 2048: the head's format)
                 if constexpr (TT) { // channels 48, 49 -> the compact planes
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                     const bool live = q == 0 && alive;
@@ -516,18 +517,18 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, nb;
                     params(mt, sc, sh, nb);
 #pragma unroll
-                    for (int nt = 0; nt < NTW; nt++) unit(kind, std::false_type{}, acc[mt][nt], acc2[mt][nt], xres[mt][nt], s0, mt, nt, sc, sh, nb);
+                    for (int nt = 0; nt < NTW; nt++) unit(kind, std::false_type{}, acc[mt][nt], xres[mt][nt], s0, mt, nt, sc, sh, nb);
                 }
                 {
                     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, nb;
                     params(3, sc, sh, nb);
 #pragma unroll
-                    for (int nt = 0; nt < NTT; nt++) unit(kind, std::true_type{}, accT[nt], acc2T[nt], xresT[nt], IS_FIRST ? s0 : s49[nt], 3, nt, sc, sh, nb);
+                    for (int nt = 0; nt < NTT; nt++) unit(kind, std::true_type{}, accT[nt], xresT[nt], IS_FIRST ? s0 : s49[nt], 3, nt, sc, sh, nb);
                 }
                 if constexpr (EXM) {
                     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, nb;
                     params(emt, sc, sh, nb);
-                    unit(kind, std::false_type{}, acce, acc2e, xrese, s0, emt, NTW, sc, sh, nb);
+                    unit(kind, std::false_type{}, acce, xrese, s0, emt, NTW, sc, sh, nb);
                 }
             };
             if constexpr (IS_FIRST) epilogue(std::integral_constant<int, 0>{});
@@ -544,10 +545,18 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
     constexpr auto I0 = std::integral_constant<int, 0>{};
     constexpr auto I1 = std::integral_constant<int, 1>{};
     constexpr auto I2 = std::integral_constant<int, 2>{};
+    constexpr auto I3 = std::integral_constant<int, 3>{};
+    (void)I3;
     if constexpr (V == 0) {
         if ((wave & 3) == 0) body(I2, I1, I0);
         else if ((wave & 3) == 1) body(I2, I1, I1);
         else if ((wave & 3) == 2) body(I2, I1, I2);
+        else body(I2, I2, I0);
+    } else if constexpr (V == 2) {
+        if (wave < 4) body(I3, I0, I0);
+        else if (wave == 4) body(I2, I1, I0);
+        else if (wave == 5) body(I2, I1, I1);
+        else if (wave == 6) body(I2, I1, I2);
         else body(I2, I2, I0);
     } else body(I2, I0, I0);
 }

@@ -19,5 +19,6 @@ template <int V> static hipError_t launch_x3d(int device, const TowerParams &tp,
 hipError_t az_launch_tower_x3d(int device, int variant, const TowerParams &tp, int grid, hipStream_t st) {
     if (variant == 0) return launch_x3d<0>(device, tp, grid, st);
     if (variant == 1) return launch_x3d<1>(device, tp, grid, st);
+    if (variant == 2) return launch_x3d<2>(device, tp, grid, st);
     return hipErrorInvalidValue;
 }

@@ -198,19 +198,20 @@ def test_fused_f32x_forward_is_fp32_grade(tag, n):
 def test_fused_f32x_outputs_do_not_depend_on_the_batch_size(tag):
     """The fp32-grade tower runs different kernels at different batch sizes: a board per workgroup for small batches
     (az_tower_x3c_kernel, <= 512 boards: four waves split a board by output-channel tile), a board per wave above
-    (az_tower_x3b_kernel), and - 6x6 boards above 1024, 8x8 boards always - eight (four) boards packed into whole column tiles
-    (az_tower_x3d_kernel).  Priors, value and tower output of a board must be the same BITS in all of them, whichever boards share
+    (az_tower_x3b_kernel), and - 6x7 and 6x6 boards above 1024, 8x8 boards always - eight (four) boards packed into whole column
+    tiles (az_tower_x3d_kernel).  Priors, value and tower output of a board must be the same BITS in all of them, whichever boards share
     its workgroup and however ragged the last one is: a generation's records may not depend on when its tail switches kernels."""
     game, net = _nets()[tag]
-    n_ref = 2048 if tag.startswith(("bt6", "bt8")) else 1024
+    packed = tag.startswith(("c4", "bt6", "bt8"))   # boards whose positions fill whole column tiles (az_tower_x3d.h)
+    n_ref = 2048 if packed else 1024
     fn = fusednet.FusedNet(net, "cuda:0", max_boards=n_ref, precision="f32x")
     torch.manual_seed(5)
     obs = (torch.rand(n_ref, 4, game.rows, game.cols, device="cuda") > 0.5).float()
     ref_p, ref_v = [t.clone() for t in fn.forward(obs)]
     torch.cuda.synchronize()
     ref_t = fn.read_tower(n_ref)
-    assert ("x3d" if tag.startswith(("bt6", "bt8")) else "x3b") in fn.kernel_label(n_ref)
-    if tag.startswith("bt6"):
+    assert ("x3d" if packed else "x3b") in fn.kernel_label(n_ref)
+    if tag.startswith(("c4", "bt6")):
         assert "x3d" in fn.kernel_label(1500) and "x3b" in fn.kernel_label(1024) and "x3c" in fn.kernel_label(300)
     elif not tag.startswith("bt8"):
         assert "x3c" in fn.kernel_label(300)
