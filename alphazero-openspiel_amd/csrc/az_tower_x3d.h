@@ -452,7 +452,6 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                 // (opaque: addresses derived from the per-tile tables are invariant across convs, and hoisted out of the conv loop every
                 //  (tile, output-channel tile) pair would hold registers for the whole kernel)
                 const int co0 = 16 * mt + 4 * q;
-                const bool alive = (opaque((int)livem) >> nt) & 1;
                 const int woff = (2 * mt + (q >> 1)) * plane_b + (q & 1) * 8;
                 f32x4 v;
                 if constexpr (!TT) {
@@ -476,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                     if constexpr (KIND == 2) {
                         half4 hi, lo;
                         split4(xv, hi, lo);
-                        if (alive) { // (the column's global row, looked up again: once per forward)
+                        if ((opaque((int)livem) >> nt) & 1) { // a board of the batch (the column's global row, looked up again: once per forward)
                             const int e = p.xd_pos[tile[nt] * 16 + l15];
                             const size_t gr = (size_t)(blockIdx.x * p.xd_nb + (e >> 8)) * p.HW + (e & 255);
                             *(half4 *)(p.xout + gr * AZ_NET_XOUT_C + co0) = hi;
@@ -489,17 +488,20 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                 }
                 half4 hi, lo;
                 split4_planes(o, hi, lo); // (between convs the lo half is unscaled; the tower OUTPUT above keeps lo x 2048: the head's format)
+                // Every lane of every tile is a real position of one of the workgroup's boards (the tiles are full), and a board past the
+                // batch computes on zero planes into cells nobody reads: no store needs a mask (x3b's padding lanes do: their cell is
+                // the halo column).  Tile T: only the lanes that hold channels 48, 49 (q == 0) store.
                 if constexpr (TT) { // channels 48, 49 -> the compact planes
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                    const bool live = q == 0 && alive;
-                    const int a6 = p6_of(nt) - (int)lds_base;
-                    *(unsigned *)(lds + (live ? a6 : trash)) = __builtin_bit_cast(u32x2, hi)[0];
-                    *(unsigned *)(lds + (live ? a6 + LO_OFF : trash + 8)) = __builtin_bit_cast(u32x2, lo)[0];
+                    if (q == 0) {
+                        const int a6 = p6_of(nt) - (int)lds_base;
+                        *(unsigned *)(lds + a6) = __builtin_bit_cast(u32x2, hi)[0];
+                        *(unsigned *)(lds + a6 + LO_OFF) = __builtin_bit_cast(u32x2, lo)[0];
+                    }
                 } else {
-                    const bool live = alive;
                     const int a0 = opaque((int)baseL[nt]) - (int)lds_base + woff;
-                    *(half4 *)(lds + (live ? a0 : trash)) = hi;
-                    *(half4 *)(lds + (live ? a0 + LO_OFF : trash + 8)) = lo;
+                    *(half4 *)(lds + a0) = hi;
+                    *(half4 *)(lds + a0 + LO_OFF) = lo;
                 }
             };
             auto epilogue = [&](auto kind) {
