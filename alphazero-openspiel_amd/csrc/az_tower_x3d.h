@@ -1,11 +1,12 @@
 // az_tower_x3d.h — az_tower_x3d_kernel: the fp32-grade (split-fp16, AZ_NET_PREC_F16X3) tower on PACKED column tiles.
 // Reference computation: ResidualBlock.forward x n_blocks of Net.forward (network.py:48-64,99-104) in eval mode.
 //
-// az_tower_x3b_kernel gives every board its own column tiles: a 6x6 breakthrough board is 36 positions in 3 x 16 columns - a quarter
-// of every MFMA, every B fragment and every epilogue lane is padding - and 8x8 boards run az_tower_x3_kernel, which still spends
-// a whole output-channel tile on channels 48, 49 (768 MFMAs per board and conv, 428 registers a wave).  Here a workgroup's NB boards
-// SHARE their tiles: NB * H * W positions fill a whole number of tiles (6x6: 8 boards, 288 = 18 tiles, 339 MFMAs per board and
-// conv against 441; 8x8: 4 boards, 256 = 16 tiles, 588 against 768), on x3b's scheme for channels 48, 49 (tiles T and X).
+// az_tower_x3b_kernel gives every board its own column tiles: a connect_four board is 42 positions in 3 x 16 columns (12.5 % of
+// every MFMA, every B fragment and every epilogue lane is padding), a 6x6 breakthrough board 36 positions in 48 columns (25 %), and
+// 8x8 boards ran az_tower_x3_kernel, which still spends a whole output-channel tile on channels 48, 49 (768 MFMAs per board and
+// conv).  Here a workgroup's NB boards SHARE their tiles: NB * H * W positions fill a whole number of tiles - connect_four: 8 boards,
+// 336 = 21 tiles, 390 MFMAs per board and conv against 441; 6x6: 8 boards, 288 = 18 tiles, 339 against 441; 8x8: 4 boards,
+// 256 = 16 tiles, 588 against 768 - on x3b's scheme for channels 48, 49 (tiles T and X) and its single accumulator per tile.
 //
 //   * WHICH positions make a tile is free - a column of an MFMA only has to be the same position in every k-step - so the host
 //     picks them for the LDS banks (az_net.hip: x3d_layout): board b's cells sit at b R + (y + 1) rs + x + 1 in a plane (halo rows
@@ -14,11 +15,13 @@
 //     every residue, lane l15 the one of residue l15.  A ds_read_b128 of a B fragment then touches 16 different bank groups for
 //     every tap (a tap moves all 16 cells by the same amount), as with x3b's row pairs.
 //   * a workgroup is EIGHT waves, two per SIMD, every one within 256 registers - no accumulator in an AGPR.  (With four waves of
-//     4-6 tiles the accumulator sets alone are 220-290 registers: the allocator then copies every final value to a vector register
-//     right behind its MFMA - s_nop 7 + four v_accvgpr_read_b32 after each MFMA of a conv's last k-step, measured 30 % of that
-//     kernel.  az_tower_x3b_kernel had the same disease: pin_acc, az_net_common.h.)  A wave owns two tiles whole (three
-//     output-channel tiles + T and X); a tile left over (6x6: tiles 16, 17) is split by output-channel tile over four waves - mt 0,
-//     1, 2 and T + X, each a role compiled on its own (selecting the A fragments by a run-time branch cost 45 spilled registers).
+//     4-6 tiles the allocator copies every final value to a vector register right behind its MFMA - s_nop 7 + four
+//     v_accvgpr_read_b32 after each MFMA of a conv's last k-step, measured 30 % of that kernel; az_tower_x3b_kernel had the same
+//     disease: pin_acc, az_net_common.h.)  A wave owns two or three tiles whole (three output-channel tiles + T and X); a tile left
+//     over is split by output-channel tile over four waves - mt 0, 1, 2 and T + X, each a role compiled on its own (selecting the A
+//     fragments by a run-time branch cost 45 spilled registers).  connect_four: waves 0-3 three tiles, waves 4-7 two and a share
+//     of tile 20; 6x6: every wave two and a share of tile 16 or 17; 8x8: two tiles a wave.  What made the three-tile role fit
+//     was the single accumulator (a third of the accumulator registers: az_net_common.h, split_pair_planes).
 //   * the waves share the planes, so a conv has two more rendezvous than x3b's: the barrier of its last k-step also separates the
 //     last plane reads from the epilogue stores, and one barrier follows the epilogue.  The shifted sum of tile X goes through
 //     ONE scratch for the workgroup (a term's destination column may be another wave's), behind a chunk barrier.
@@ -27,11 +30,9 @@
 //     the next k-step are fetched right behind them into the same registers (waits are counted: lgkmcnt(N), N = the reads issued
 //     since); A fragments of tiles 0..2 keep x3b's two-slot ring, those of T and X have one set; the per-k-step address offsets
 //     are compile-time constants selected per lane where they are used, not a table of registers.
-//   * NOT built for connect_four (8 boards = 21 tiles would take 12.5 % of the MFMAs out): 2.6 tiles a wave are 1176 accumulator
-//     registers per workgroup + fragments + tables - more than 8 x 256; with four waves of 5.25 tiles ~500 a wave, 385-600 spilled
-//     (210 with the residual stream moved to a workspace in global memory).  DESIGN_HISTORY.md, round 4.
 // Every accumulator sees the same MFMAs in the same order as in az_tower_x3b_kernel / az_tower_x3c_kernel and the epilogue is the
-// same arithmetic: on row-pair boards a board's outputs are the same BITS in all three (tests/test_fused_net.py).
+// same arithmetic: on row-pair boards a board's outputs are the same BITS in all three (tests/test_fused_net.py).  The epilogue's plane
+// stores need no mask here: every lane of a tile is a real position, and a board past the batch computes on zero planes.
 #pragma once
 #include "az_net_common.h"
 
@@ -514,24 +515,20 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                     nb = *(const f32x4 *)(lds + (ep_base - lds_base) + 768 + mt * 64);
                 };
                 const f32x2 s0 = {0.f, 0.f};
+                // every tile's parameters in ONE batch of LDS reads (a read-wait per tile is five exposed round trips per epilogue)
+                f32x4 sc[4], sh[4], nb[4];
 #pragma unroll
-                for (int mt = 0; mt < 3; mt++) {
-                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, nb;
-                    params(mt, sc, sh, nb);
+                for (int mt = 0; mt < 4; mt++) {
+                    sc[mt] = sh[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    params(mt, sc[mt], sh[mt], nb[mt]);
+                }
 #pragma unroll
-                    for (int nt = 0; nt < NTW; nt++) unit(kind, std::false_type{}, acc[mt][nt], xres[mt][nt], s0, mt, nt, sc, sh, nb);
-                }
-                {
-                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, nb;
-                    params(3, sc, sh, nb);
+                for (int mt = 0; mt < 3; mt++)
 #pragma unroll
-                    for (int nt = 0; nt < NTT; nt++) unit(kind, std::true_type{}, accT[nt], xresT[nt], IS_FIRST ? s0 : s49[nt], 3, nt, sc, sh, nb);
-                }
-                if constexpr (EXM) {
-                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, nb;
-                    params(emt, sc, sh, nb);
-                    unit(kind, std::false_type{}, acce, xrese, s0, emt, NTW, sc, sh, nb);
-                }
+                    for (int nt = 0; nt < NTW; nt++) unit(kind, std::false_type{}, acc[mt][nt], xres[mt][nt], s0, mt, nt, sc[mt], sh[mt], nb[mt]);
+#pragma unroll
+                for (int nt = 0; nt < NTT; nt++) unit(kind, std::true_type{}, accT[nt], xresT[nt], IS_FIRST ? s0 : s49[nt], 3, nt, sc[3], sh[3], nb[3]);
+                if constexpr (EXM) unit(kind, std::false_type{}, acce, xrese, s0, emt, NTW, sc[emt], sh[emt], nb[emt]);
             };
             if constexpr (IS_FIRST) epilogue(std::integral_constant<int, 0>{});
             else {
