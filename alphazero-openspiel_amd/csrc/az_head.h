@@ -1,5 +1,5 @@
 // az_head.h — fc1 + softmax + tanh of Net.forward (network.py:61-64): az_head_kernel (small action spaces),
-// az_head_logits_kernel + az_head_softmax_kernel (breakthrough's 433 / 769 outputs).
+// az_head_gemm_kernel + az_head_softmax_kernel (breakthrough's 433 / 769 outputs).
 #pragma once
 #include "az_head_params.h"
 
@@ -114,178 +114,210 @@ template <bool X3> __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kerne
 }
 
 // Large action spaces (breakthrough: 433 / 769 outputs = 28 / 49 output tiles): fc1 is a real GEMM there,
-//   logits[board][o] = sum_k x[board][k] * Wfc[o][k],   M = boards, N = n_ot * 16, K = H*W*64.
-// Round 1's kernel (16 boards x 8 output tiles per workgroup, K split over the waves, every wave pulling its own weight
-// fragments from L2) re-read the 2-6 MB of fc weights once per 16 boards: 45 us (6x6, 4096 boards) / 82 us (8x8, 2048
-// boards) at 7 % of the matrix peak - 18 % of those configurations' GPU time (profiles/r2_c3_kernel_stats.csv).
-// Now: a workgroup = 4 waves = 128 boards x HEAD_OTG output tiles; every wave owns 2 x 16 boards over the WHOLE K (no
-// cross-wave reduction; a weight fragment read from LDS feeds two MFMAs); the weight fragments of a chunk of HEAD_CK k-steps are brought into LDS ONCE per workgroup by LDS-DMA
-// (a fragment is one contiguous KiB = one wave-instruction), double buffered; A fragments come straight from the tower
-// output (each wave reads only its own boards) and are prefetched a chunk ahead.  L2 traffic for the weights drops 4x.
-// HEAD_MT: board tiles (x16 boards) per wave - every weight fragment read from LDS feeds HEAD_MT MFMAs
-template <bool X3, int HEAD_MT> __global__ __launch_bounds__(256) void az_head_logits_kernel(HeadParams p, float *__restrict__ logits_g) {
+//   logits[board][o] = sum_k x[board][k] * Wfc[o][k],   M = boards, N = n_ot * 16, K = H*W*64,
+// tiled with BOTH operands staged through LDS.  A workgroup owns HG_BT x 16 = 128 boards x up to HG_OT x 16 = 128 outputs over HALF
+// of K (HG_KSPLIT = 2: 2048 boards x 769 outputs are only 112 such tiles for 256 CUs; az_head_softmax_kernel adds the two partial
+// sums, always in the same order, so a board's result does not depend on the batch).  The output tiles are dealt evenly to the
+// groups (49 = 7 x 7, 28 = 4 x 7: no padding tile is multiplied).  Eight computing waves (wm, wn) = 32 boards x 4 or 3 output tiles
+// over the workgroup's K: per k-step 32 KiB come in for 128 x 128 x 32 products, 12 fragment reads feed 24 (21) MFMAs; HG_LOADERS
+// more waves do nothing but issue the LDS-DMA (a computing wave that issues its own share spends MFMA slots on it: 51 -> 45 us).
+//   * a weight fragment is one contiguous KiB of the packed fc stream;
+//   * an A fragment is 16 boards x 64 bytes of the tower output.  Lane 4r + j fetches octet j ^ 2 (r >> 3) of board r (four
+//     neighbouring lanes = 64 contiguous bytes, see frag_from_rows), the DMA drops it at byte 16 (4r + j) of the KiB, and the MFMA
+//     lane (q, r) reads byte 16 (4r + (q ^ 2 (r >> 3))).  ds_read_b128 serves the lanes in the groups {0-3, 12-15, 20-27}, {4-11,
+//     16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS): a group holds every board r once, with octet q0 + [4 <= r < 12] or q0 + 1 -
+//     [4 <= r < 12], and its sixteen 16-byte bank groups 4 (r & 3) + (q ^ 2 (r >> 3)) are all different - no bank conflict, no
+//     ds_bpermute;
+//   * HG_RING k-step slots; the loaders wait with counted vmcnt (a __syncthreads() would drain the k-steps in flight), one bare
+//     barrier per k-step hands a slot from the loaders to the computing waves and the slot behind it back.
+// Board tiles past n_boards are fetched clamped and never multiplied (wave-uniform), never stored.
+// History: round 1 read the fc weights once per 16 boards (45 / 82 us for 4096 6x6 / 2048 8x8 boards); rounds 2-3 ran 64 boards x 64
+// outputs per workgroup with the A fragments straight from L2 (44 / 85 us: 832 MB through the L2s per 2048 8x8 boards, and a branch
+// and a wait around every MFMA of the 3-tile waves would have been the next problem); this kernel: 32 / 43 us.
+#define HG_BT 8
+#define HG_OT 8
+#define HG_KSPLIT 2
+#define HG_RING 4
+#ifndef HG_LOADERS
+#define HG_LOADERS 4 // waves that only issue the LDS-DMA (2 measured the same)
+#endif
+template <bool X3> __global__ __launch_bounds__((8 + HG_LOADERS) * 64) void az_head_gemm_kernel(HeadParams p, float *__restrict__ logits_g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int CK = X3 ? 2 : 4;                       // k-steps per chunk: 16 KiB of weight fragments either way
     constexpr int NPART = X3 ? 2 : 1;
-    constexpr int FRAGS = CK * HEAD_OTG * NPART;         // KiB fragments per chunk: [part][ksl][o]
-    constexpr int CHUNK_B = FRAGS * 1024;
-    constexpr int PER = FRAGS / 4 + CK * NPART * HEAD_MT; // vector-memory operations one wave issues per chunk
-    static_assert(FRAGS % 4 == 0 && (HEAD_RING - 2) * PER < 64, "pieces split evenly over the 4 waves; the counted waits fit vmcnt");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l15 = lane & 15;
-    // XCD-aware tile order.  Workgroup L runs on XCD L % 8 (each XCD has its own L2): the column groups of one board tile get
-    // CONSECUTIVE slots of ONE XCD, so the tower output of those boards comes in from the Infinity Cache / HBM once and is
-    // re-read from that XCD's L2 by the other column groups (a plain 2-D grid re-fetched it once per column group).
-    const int n_cg = (p.n_ot + HEAD_OTG - 1) / HEAD_OTG;
+    constexpr int PIECES = (HG_BT + HG_OT) * NPART; // KiB fragments per k-step: [A part][board tile], [W part][output tile]
+    constexpr int SLOT_B = PIECES * 1024;
+    constexpr int NLOAD = HG_LOADERS;                  // waves that issue pieces
+    constexpr int PER = PIECES / NLOAD;               // per loading wave and k-step
+    static_assert((NLOAD == 2 || NLOAD == 4) && PIECES % NLOAD == 0 && HG_BT == 8 && HG_OT == 8 && (HG_RING - 2) * PER < 64, "piece f = NLOAD i + loader; the counted waits fit vmcnt");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, l15 = lane & 15;
+    // wave (wm, wn): board tiles 2 wm, 2 wm + 1 x output tiles 4 wn .. 4 wn + 3 of the group; the two waves of a SIMD (w, w + 4) take
+    // one half of the group's tiles each (a group of 7: 4 + 3 on every SIMD)
+    const int wm = (wave & 7) >> 1, wn = (wave ^ (wave >> 2)) & 1;
+    // XCD-aware order.  Workgroup L runs on XCD L % 8 (each XCD has its own L2): the workgroups of one board tile get consecutive
+    // slots of ONE XCD, so those boards' rows come in from the Infinity Cache once and are shared in that L2
+    const int n_cg = (p.n_ot + HG_OT - 1) / HG_OT, ot_per = (p.n_ot + n_cg - 1) / n_cg, per_bt = n_cg * HG_KSPLIT;
     const int lin = blockIdx.x, xcd = lin & 7, j = lin >> 3;
-    const int bt = (j / n_cg) * 8 + xcd;
-    if (bt * 64 * HEAD_MT >= p.n_boards) return; // (whole workgroup: before any barrier)
-    const int b0 = (bt * 4 + wave) * 16 * HEAD_MT, og = (j % n_cg) * HEAD_OTG;
+    const int bt = (j / per_bt) * 8 + xcd;
+    if (bt * 16 * HG_BT >= p.n_boards) return; // (whole workgroup: before any barrier)
+    const int og = ((j % per_bt) / HG_KSPLIT) * ot_per, kh = (j % per_bt) % HG_KSPLIT;
+    const int n_og = p.n_ot - og < ot_per ? p.n_ot - og : ot_per; // output tiles of this group: 49 = 7 x 7, 28 = 4 x 7 (no padding tile)
     const int K = p.HW * AZ_NET_XOUT_C, NP = p.n_ot * 16;
-    const int n_chunks = (p.ksteps + CK - 1) / CK;
-    const _Float16 *xrow[HEAD_MT], *xrow_lo[HEAD_MT];
+    const int ks_per = (p.ksteps + HG_KSPLIT - 1) / HG_KSPLIT, ks0 = kh * ks_per;
+    const int nk = (p.ksteps - ks0 < ks_per ? p.ksteps - ks0 : ks_per);
+    const bool loader = wave >= 8;
+    // a loading wave's PER pieces of a k-step: base address at k-step 0 and halves per k-step
+    const _Float16 *src0[PER];
+    int kstride[PER], dst[PER];
+    if (loader) {
 #pragma unroll
-    for (int m = 0; m < HEAD_MT; m++) {
-        int row = b0 + 16 * m + (lane >> 2); // (load mapping of frag_from_rows)
-        if (row >= p.n_boards) row = p.n_boards - 1; // clamp: computed, never stored
-        xrow[m] = p.x + (size_t)row * K + 8 * (lane & 3);
-        xrow_lo[m] = X3 ? p.x_lo + (size_t)row * K + 8 * (lane & 3) : nullptr;
-    }
-    half8 a[HEAD_RING][CK][HEAD_MT], al[HEAD_RING][X3 ? CK : 1][X3 ? HEAD_MT : 1];
-    // chunk c -> LDS slot `slot` (compile-time) + the A fragments of its k-steps.  Out-of-range tiles / k-steps re-fetch a valid
-    // fragment (their products are never stored / never accumulated).
-    auto issue_chunk = [&](int c, auto slot_c) {
-        constexpr int slot = decltype(slot_c)::value;
-#pragma unroll
-        for (int i = 0; i < FRAGS / 4; i++) {
-            const int f = i * 4 + wave;
-            const int part = f / (CK * HEAD_OTG), ksl = (f / HEAD_OTG) % CK, o = f % HEAD_OTG;
-            int ot = og + o, ks = c * CK + ksl;
-            ot = ot < p.n_ot ? ot : p.n_ot - 1;
-            ks = ks < p.ksteps ? ks : p.ksteps - 1;
-            const _Float16 *src = (part ? p.fc_w_lo : p.fc_w) + (((size_t)ot * p.ksteps + ks) * 64 + lane) * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(lds + slot * CHUNK_B + f * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int ksl = 0; ksl < CK; ksl++) {
-            int ks = c * CK + ksl;
-            ks = ks < p.ksteps ? ks : p.ksteps - 1;
-#pragma unroll
-            for (int m = 0; m < HEAD_MT; m++) {
-                // asm, not a C++ load: the counted s_waitcnt below relies on the ISSUE ORDER of every vector-memory operation
-                // (a compiler-scheduled load could be sunk towards its use and shift the count)
-                {
-                    half8 &dst = a[slot][ksl][m];
-                    const _Float16 *src = xrow[m] + 32 * ks;
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
-                }
-                if constexpr (X3) {
-                    half8 &dst = al[slot][ksl][m];
-                    const _Float16 *src = xrow_lo[m] + 32 * ks;
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
-                }
+        for (int i = 0; i < PER; i++) {
+            const int f = NLOAD * i + (wave & (NLOAD - 1));
+            dst[i] = f * 1024;
+            if (f < HG_BT * NPART) {
+                const int r = lane >> 2;
+                int row = (bt * HG_BT + f % HG_BT) * 16 + r;
+                if (row >= p.n_boards) row = p.n_boards - 1;
+                src0[i] = (f / HG_BT ? p.x_lo : p.x) + (size_t)row * K + 8 * ((lane & 3) ^ ((r >> 3) << 1));
+                kstride[i] = 32;
+            } else {
+                const int g = f - HG_BT * NPART;
+                int ot = og + g % HG_OT;
+                ot = ot < p.n_ot ? ot : p.n_ot - 1; // (a tile past the group: a valid fragment, never multiplied)
+                src0[i] = (g / HG_OT ? p.fc_w_lo : p.fc_w) + ((size_t)ot * p.ksteps * 64 + lane) * 8;
+                kstride[i] = 512;
             }
         }
+    }
+    auto issue = [&](int ks, int slot) {
+#pragma unroll
+        for (int i = 0; i < PER; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0[i] + (size_t)ks * kstride[i]),
+                                             (__attribute__((address_space(3))) void *)(lds + slot * SLOT_B + dst[i]), 16, 0, 0);
     };
-    // The biases come in HERE.  vmcnt counts stores too on this chip: a bias load between the output tiles' stores waited for the
-    // stores before it - four store round trips in a row, 65 % of the kernel (clock64 probes, 6x6).
-    float bias_o[HEAD_OTG];
+    // The hand-over, per k-step i: barrier i tells the computing waves that k-step i + 1 is in LDS and the loaders that everybody has
+    // read k-step i (a computing wave reads k-step i + 1 into its second register set right behind barrier i, then multiplies k-step
+    // i: the reads' latency hides behind the MFMAs).  One barrier before the loop hands over k-step 0.
+    if (loader) {
 #pragma unroll
-    for (int o = 0; o < HEAD_OTG; o++) bias_o[o] = p.fc_b[16 * (og + o < p.n_ot ? og + o : p.n_ot - 1) + l15];
-    f32x4 acc[HEAD_MT][HEAD_OTG], acc2[X3 ? HEAD_MT : 1][X3 ? HEAD_OTG : 1];
-#pragma unroll
-    for (int m = 0; m < HEAD_MT; m++)
-#pragma unroll
-        for (int o = 0; o < HEAD_OTG; o++) {
-            acc[m][o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (X3) acc2[m][o] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    static_for<HEAD_RING - 1>([&](auto s_c) {
-        if (decltype(s_c)::value < n_chunks) issue_chunk(decltype(s_c)::value, s_c);
-    });
-    for (int c0 = 0; c0 < n_chunks; c0 += HEAD_RING) {
-        static_for<HEAD_RING>([&](auto s_c) {
-            constexpr int slot = decltype(s_c)::value;
-            const int c = c0 + slot;
-            if (c < n_chunks) {
-                // chunk c has landed once at most the operations of the (up to RING - 2) younger chunks are outstanding
-                const int younger = n_chunks - 1 - c < HEAD_RING - 2 ? n_chunks - 1 - c : HEAD_RING - 2;
-                static_for<HEAD_RING - 1>([&](auto y_c) { // (a literal operand per possible count)
+        for (int s = 0; s < HG_RING - 1; s++)
+            if (s < nk) issue(ks0 + s, s);
+        for (int i = -1; i < nk; i++) {
+            if (i + 1 < nk) { // k-step i + 1 has landed once at most the pieces of the (up to RING - 2) younger k-steps are outstanding
+                const int younger = nk - 2 - i < HG_RING - 2 ? nk - 2 - i : HG_RING - 2;
+                static_for<HG_RING - 1>([&](auto y_c) { // (a literal operand per possible count)
                     constexpr int y = decltype(y_c)::value;
                     if (younger == y) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(y * PER) : "memory");
                 });
-                // a BARE barrier: __syncthreads() carries a fence that drains vmcnt to 0 and with it the chunks in flight
-                __builtin_amdgcn_s_barrier(); // everybody's pieces of chunk c are in LDS, and the slot of chunk c - 1 is free again
-                asm volatile("" ::: "memory");
-                if (c + HEAD_RING - 1 < n_chunks) issue_chunk(c + HEAD_RING - 1, std::integral_constant<int, (slot + HEAD_RING - 1) % HEAD_RING>{});
-                const unsigned char *wb = lds + slot * CHUNK_B + lane * 16;
-                // One straight-line block per chunk: the A fragments' lane exchange and ALL the chunk's weight-fragment reads go out first,
-                // the MFMAs follow behind counted waits (a branch per k-step left each k-step waiting out two LDS round trips).  A k-step
-                // past the end (odd H*W only) multiplies a zero A fragment.
-                half8 af[CK][HEAD_MT], afl[X3 ? CK : 1][X3 ? HEAD_MT : 1];
-                half8 w[CK][HEAD_OTG], wl[X3 ? CK : 1][X3 ? HEAD_OTG : 1];
-                const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (i + HG_RING < nk) issue(ks0 + i + HG_RING, (i + HG_RING) % HG_RING); // into the slot of k-step i
+        }
+        return;
+    }
+    // board tiles / output tiles this wave multiplies (wave-uniform): both board tiles and 4 or 3 output tiles in all but the last
+    // board tile of a ragged batch and the last group of an odd split - those take the predicated loop
+    const int n_m = (bt * HG_BT + 2 * wm + 1) * 16 < p.n_boards ? 2 : (bt * HG_BT + 2 * wm) * 16 < p.n_boards ? 1 : 0;
+    const int n_o = n_og - 4 * wn < 0 ? 0 : n_og - 4 * wn > 4 ? 4 : n_og - 4 * wn;
+    // the biases come in HERE (vmcnt counts stores too: a bias load between the output tiles' stores waits for the stores before it);
+    // they ride on the first half of K
+    float bias_o[4];
 #pragma unroll
-                for (int ksl = 0; ksl < CK; ksl++) {
-                    const bool live = c * CK + ksl < p.ksteps;
+    for (int o = 0; o < 4; o++) bias_o[o] = kh == 0 && o < n_o ? p.fc_b[16 * (og + 4 * wn + o) + l15] : 0.f;
+    f32x4 acc[2][4], acc2[X3 ? 2 : 1][X3 ? 4 : 1];
 #pragma unroll
-                    for (int m = 0; m < HEAD_MT; m++) {
-                        af[ksl][m] = frag_from_rows(live ? a[slot][ksl][m] : zero8, lane);
-                        if constexpr (X3) afl[ksl][m] = frag_from_rows(live ? al[slot][ksl][m] : zero8, lane);
-                    }
-                }
+    for (int m = 0; m < 2; m++)
 #pragma unroll
-                for (int ksl = 0; ksl < CK; ksl++)
+        for (int o = 0; o < 4; o++) {
+            acc[m][o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (X3) acc2[m][o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    const int a_off = (4 * l15 + (q ^ ((l15 >> 3) << 1))) * 16 + 2 * wm * 1024;
+    const int w_off = (HG_BT * NPART + 4 * wn) * 1024 + lane * 16;
+    // NO = 4, 3: straight-line k-step for two board tiles x NO output tiles; NO = 0: every tile behind a (scalar) branch
+    auto kloop = [&](auto no_c) {
+        constexpr int NO = decltype(no_c)::value, NOT = NO ? NO : 4;
+        half8 af[2], afl[X3 ? 2 : 1], w[4], wl[X3 ? 4 : 1];
+        auto read = [&](int i) {
+            const unsigned char *sb = lds + (i % HG_RING) * SLOT_B;
 #pragma unroll
-                    for (int o = 0; o < HEAD_OTG; o++) {
-                        w[ksl][o] = *(const half8 *)(wb + (ksl * HEAD_OTG + o) * 1024);
-                        if constexpr (X3) wl[ksl][o] = *(const half8 *)(wb + ((CK + ksl) * HEAD_OTG + o) * 1024);
-                    }
+            for (int m = 0; m < 2; m++) {
+                af[m] = *(const half8 *)(sb + a_off + m * 1024);
+                if constexpr (X3) afl[m] = *(const half8 *)(sb + a_off + (HG_BT + m) * 1024);
+            }
 #pragma unroll
-                for (int ksl = 0; ksl < CK; ksl++)
+            for (int o = 0; o < NOT; o++) {
+                w[o] = *(const half8 *)(sb + w_off + o * 1024);
+                if constexpr (X3) wl[o] = *(const half8 *)(sb + w_off + (HG_OT + o) * 1024);
+            }
+        };
+        auto step = [&](int i) {
+            read(i);
+            // three sweeps over the wave's tiles: the two MFMAs into acc2[m][o] are a sweep apart (back to back, the second waits out
+            // the first one's latency)
 #pragma unroll
-                    for (int o = 0; o < HEAD_OTG; o++)
+            for (int pass = 0; pass < (X3 ? 3 : 1); pass++)
 #pragma unroll
-                        for (int m = 0; m < HEAD_MT; m++) {
-                            acc[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ksl][m], w[ksl][o], acc[m][o], 0, 0, 0);
+                for (int o = 0; o < NOT; o++)
+#pragma unroll
+                    for (int m = 0; m < 2; m++)
+                        if (NO || (o < n_o && m < n_m)) {
+                            if (pass == 0) acc[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], w[o], acc[m][o], 0, 0, 0);
                             if constexpr (X3) {
-                                acc2[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ksl][m], wl[ksl][o], acc2[m][o], 0, 0, 0);
-                                acc2[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afl[ksl][m], w[ksl][o], acc2[m][o], 0, 0, 0);
+                                if (pass == 1) acc2[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], wl[o], acc2[m][o], 0, 0, 0);
+                                if (pass == 2) acc2[m][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afl[m], w[o], acc2[m][o], 0, 0, 0);
                             }
                         }
-            }
-        });
-    }
-    // D: row = 4q + r -> board b0 + 16 m + 4q + r, col = l15 -> output 16 (og + o) + l15
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // k-step i + 1 is in LDS; the loaders may refill the slot of k-step i
+            asm volatile("" ::: "memory");
+        };
+        __builtin_amdgcn_s_barrier(); // k-step 0 is in LDS
+        asm volatile("" ::: "memory");
+        for (int i = 0; i < nk; i++) step(i);
+    };
+    if (n_m == 2 && n_o == 4) kloop(std::integral_constant<int, 4>{});
+    else if (n_m == 2 && n_o == 3) kloop(std::integral_constant<int, 3>{});
+    else kloop(std::integral_constant<int, 0>{});
+    // D: row = 4q + r -> board, col = l15 -> output 16 (og + 4 wn + o) + l15
+    float *out = logits_g + (size_t)kh * p.n_boards * NP;
 #pragma unroll
-    for (int o = 0; o < HEAD_OTG; o++) {
-        if (og + o >= p.n_ot) continue;
-        const int col = 16 * (og + o) + l15;
+    for (int o = 0; o < 4; o++) {
+        if (o >= n_o) continue;
+        const int col = 16 * (og + 4 * wn + o) + l15;
         const float bias = bias_o[o];
 #pragma unroll
-        for (int m = 0; m < HEAD_MT; m++) {
+        for (int m = 0; m < 2; m++) {
             f32x4 v = acc[m][o];
             if constexpr (X3) v = v + acc2[m][o] * (1.0f / 2048.0f);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int b = b0 + 16 * m + 4 * q + r;
-                if (b < p.n_boards) logits_g[(size_t)b * NP + col] = v[r] + bias;
+                const int b = (bt * HG_BT + 2 * wm + m) * 16 + 4 * q + r;
+                if (b < p.n_boards) out[(size_t)b * NP + col] = v[r] + bias;
             }
         }
     }
 }
 // softmax over the first A logits, tanh of logit A: one WAVE per board, the board's logits held in registers
 #define HEAD_SM_MAX 13 // ceil((12 * 64 + 1) / 64): A <= 768 (boards of <= 64 cells)
-template <bool X3> __global__ __launch_bounds__(256) void az_head_softmax_kernel(HeadParams p, const float *__restrict__ logits_g) {
+// NSPLIT: partial sums over K to add (az_head_gemm_kernel: HG_KSPLIT, buffers n_boards * NP floats apart)
+template <bool X3, int NSPLIT> __global__ __launch_bounds__(256) void az_head_softmax_kernel(HeadParams p, const float *__restrict__ logits_g) {
     const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6), NP = p.n_ot * 16;
     if (b >= p.n_boards) return;
     const float *lg = logits_g + (size_t)b * NP;
+    const size_t part = (size_t)p.n_boards * NP;
+    auto logit = [&](int o) {
+        float v = lg[o];
+#pragma unroll
+        for (int s = 1; s < NSPLIT; s++) v += lg[s * part + o];
+        return v;
+    };
     float v[HEAD_SM_MAX];
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < HEAD_SM_MAX; i++) {
         const int o = i * 64 + lane;
-        v[i] = o < p.A ? lg[o] : -INFINITY;
+        v[i] = o < p.A ? logit(o) : -INFINITY;
         mx = fmaxf(mx, v[i]);
     }
 #pragma unroll
@@ -305,5 +337,5 @@ template <bool X3> __global__ __launch_bounds__(256) void az_head_softmax_kernel
         const int o = i * 64 + lane;
         if (o < p.A) out[o] = X3 ? v[i] / sum : v[i] * inv;
     }
-    if (lane == 0) p.values[b] = tanhf(lg[p.A]);
+    if (lane == 0) p.values[b] = tanhf(logit(p.A));
 }

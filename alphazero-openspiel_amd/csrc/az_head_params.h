@@ -12,10 +12,8 @@ struct HeadParams {
     float *priors, *values;
 };
 
-#define OTG 8       // output tiles per pass of az_head_kernel; action spaces with more tiles take the logits + softmax kernels
+#define OTG 8       // output tiles per pass of az_head_kernel; action spaces with more tiles take az_head_gemm_kernel + az_head_softmax_kernel
 #define HEAD_NW 8   // waves per workgroup of az_head_kernel: the K reduction is split over them
-#define HEAD_OTG 4  // output tiles (x16 outputs) per workgroup of az_head_logits_kernel
-#define HEAD_RING 4 // weight chunks resident in LDS: chunk c is multiplied while c+1 .. c+RING-2 are in flight
 
 // Launchers (one per translation unit, so the kernel families compile side by side).  `device` indexes the per-device
 // "dynamic LDS attribute set" flags; every launcher returns hipGetLastError() of its launch.

@@ -555,7 +555,7 @@ extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
     }
     if (n->logits) (void)hipFree(n->logits);
     n->logits = nullptr;
-    if (n->n_ot > OTG) NCHK(n, hipMalloc((void **)&n->logits, (size_t)max_boards * n->n_ot * 16 * sizeof(float)));
+    if (n->n_ot > OTG) NCHK(n, hipMalloc((void **)&n->logits, (size_t)max_boards * n->n_ot * 16 * sizeof(float) * 2)); // x 2: HG_KSPLIT partial sums (az_head_gemm_kernel)
     n->max_boards = max_boards;
     return AZ_OK;
 }
@@ -634,13 +634,13 @@ extern "C" const char *az_net_kernel_label(const az_net *n, int32_t n_boards) {
     const NetDispatch dp = net_dispatch(n, n_boards < 1 ? n->max_boards : n_boards);
     if (n->precision == AZ_NET_PREC_F16X3) {
         if (dp.x3c_head) return "az_tower_x3c_kernel (fc1 + softmax + tanh in the same launch)";
-        if (dp.x3c) return big ? "az_tower_x3c_kernel + az_head_logits_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3c_kernel + az_head_kernel<X3>";
-        if (dp.x3d) return big ? "az_tower_x3d_kernel + az_head_logits_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3d_kernel + az_head_kernel<X3>";
-        if (n->x3b) return big ? "az_tower_x3b_kernel + az_head_logits_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3b_kernel + az_head_kernel<X3>";
-        return big ? "az_tower_x3_kernel + az_head_logits_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3_kernel + az_head_kernel<X3>";
+        if (dp.x3c) return big ? "az_tower_x3c_kernel + az_head_gemm_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3c_kernel + az_head_kernel<X3>";
+        if (dp.x3d) return big ? "az_tower_x3d_kernel + az_head_gemm_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3d_kernel + az_head_kernel<X3>";
+        if (n->x3b) return big ? "az_tower_x3b_kernel + az_head_gemm_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3b_kernel + az_head_kernel<X3>";
+        return big ? "az_tower_x3_kernel + az_head_gemm_kernel<X3> + az_head_softmax_kernel<X3>" : "az_tower_x3_kernel + az_head_kernel<X3>";
     }
-    if (dp.f16c) return big ? "az_tower_f16c_kernel + az_head_logits_kernel + az_head_softmax_kernel" : "az_tower_f16c_kernel + az_head_kernel";
-    return big ? "az_tower_kernel + az_head_logits_kernel + az_head_softmax_kernel" : "az_tower_kernel + az_head_kernel";
+    if (dp.f16c) return big ? "az_tower_f16c_kernel + az_head_gemm_kernel + az_head_softmax_kernel" : "az_tower_f16c_kernel + az_head_kernel";
+    return big ? "az_tower_kernel + az_head_gemm_kernel + az_head_softmax_kernel" : "az_tower_kernel + az_head_kernel";
 }
 
 extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float *values, int32_t n_boards, void *stream) {

@@ -22,7 +22,7 @@
 #include "az_tower_f16.h"
 
 // RING: weight-chunk buffers in LDS: chunk c + RING - 1 is requested while chunk c is multiplied; the waits are counted (vmcnt) and
-// the barriers bare, as in az_head_logits_kernel.
+// the barriers bare, as in az_head_gemm_kernel.
 template <int NT, int CK, int RING>
 __global__ __launch_bounds__(256, 1) void az_tower_f16c_kernel(TowerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
