@@ -27,7 +27,7 @@ template <bool X3> __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kerne
     float *logits = (float *)(lds + HEAD_NW * OTG * 64 * 16); // [16][n_ot*16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * 16;
-    const int K = p.HW * AZ_NET_XOUT_C, NP = p.n_ot * 16;
+    const int K = p.K, NP = p.n_ot * 16;
     int row = b0 + (lane >> 2); // (load mapping of frag_from_rows)
     if (row >= p.n_boards) row = p.n_boards - 1; // clamp: computed, never stored
     const _Float16 *xrow = p.x + (size_t)row * K + 8 * (lane & 3);
@@ -114,7 +114,7 @@ template <bool X3> __global__ __launch_bounds__(HEAD_NW * 64) void az_head_kerne
 }
 
 // Large action spaces (breakthrough: 433 / 769 outputs = 28 / 49 output tiles): fc1 is a real GEMM there,
-//   logits[board][o] = sum_k x[board][k] * Wfc[o][k],   M = boards, N = n_ot * 16, K = H*W*64,
+//   logits[board][o] = sum_k x[board][k] * Wfc[o][k],   M = boards, N = n_ot * 16, K = H*W*52 (az_net_create),
 // tiled with BOTH operands staged through LDS.  A workgroup owns HG_BT x 16 = 128 boards x up to HG_OT x 16 = 128 outputs over HALF
 // of K (HG_KSPLIT = 2: 2048 boards x 769 outputs are only 112 such tiles for 256 CUs; az_head_softmax_kernel adds the two partial
 // sums, always in the same order, so a board's result does not depend on the batch).  The output tiles are dealt evenly to the
@@ -161,7 +161,7 @@ template <bool X3> __global__ __launch_bounds__((8 + HG_LOADERS) * 64) void az_h
     if (bt * 16 * HG_BT >= p.n_boards) return; // (whole workgroup: before any barrier)
     const int og = ((j % per_bt) / HG_KSPLIT) * ot_per, kh = (j % per_bt) % HG_KSPLIT;
     const int n_og = p.n_ot - og < ot_per ? p.n_ot - og : ot_per; // output tiles of this group: 49 = 7 x 7, 28 = 4 x 7 (no padding tile)
-    const int K = p.HW * AZ_NET_XOUT_C, NP = p.n_ot * 16;
+    const int K = p.K, NP = p.n_ot * 16;
     const int ks_per = (p.ksteps + HG_KSPLIT - 1) / HG_KSPLIT, ks0 = kh * ks_per;
     const int nk = (p.ksteps - ks0 < ks_per ? p.ksteps - ks0 : ks_per);
     const bool loader = wave >= 8;

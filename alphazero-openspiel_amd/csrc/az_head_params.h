@@ -5,7 +5,8 @@
 
 struct HeadParams {
     int HW, A, n_ot, ksteps, n_boards;
-    const _Float16 *x;    // [B][HW*64]
+    int K;                // halves per board row of x: HW * (channel stride of the tower output); ksteps = ceil(K / 32)
+    const _Float16 *x;    // [B][K]
     const _Float16 *fc_w; // [n_ot][ksteps][64][8]
     const _Float16 *x_lo, *fc_w_lo; // f16x3: the lo halves (scaled by 2048), same layouts
     const float *fc_b;

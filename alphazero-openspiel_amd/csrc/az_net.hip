@@ -41,6 +41,7 @@ struct az_net {
     _Float16 *conv_w = nullptr, *fc_w = nullptr, *xout = nullptr;
     _Float16 *fc_w_lo = nullptr, *xout_lo = nullptr; // f16x3 only
     float *epi = nullptr, *fc_b = nullptr, *skip_w = nullptr, *logits = nullptr;
+    int xc = AZ_NET_XOUT_C, fc_ksteps = 0; // channel stride of xout / k-steps of fc1 (az_net_create)
     float in_affine[16];
     int max_boards = 0;
     int bpw_max = 0, lds_head = 0, n_ot = 0, r3 = 16;
@@ -397,7 +398,28 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
         delete n;
         return AZ_E_HIP;
     }
-    size_t fw = (size_t)n->n_ot * (HW * AZ_NET_XOUT_C / 32) * 64 * 8 * 2, fb = (size_t)n->n_ot * 16 * 4;
+    // Channel stride of the tower output = K index of fc1.  The descriptor's fc stream is laid out for 64 (AZ_NET_XOUT_C: 50 channels
+    // padded to two 32-wide k-steps per cell).  Where fc1 is a real GEMM (az_head_gemm_kernel) the 14 padding channels are 22 % of its
+    // MFMAs and bytes: those nets keep 52 channels per cell (8-byte stores stay aligned; H*W even keeps the board rows 16-byte aligned)
+    // and the stream is repacked here.  The small heads (az_head_kernel, az_head_fused.h) walk k-steps of (cell, channel half): 64.
+    n->xc = (n->n_ot > OTG && HW % 2 == 0 && d.n_filters <= 52) ? 52 : AZ_NET_XOUT_C; // (the reference's nets have 50 filters)
+    n->fc_ksteps = (HW * n->xc + 31) / 32;
+    const int ks64 = HW * AZ_NET_XOUT_C / 32;
+    size_t fw = (size_t)n->n_ot * n->fc_ksteps * 64 * 8 * 2, fb = (size_t)n->n_ot * 16 * 4;
+    std::vector<uint16_t> fc_re, fc_re_lo;
+    auto repack_fc = [&](const uint16_t *src, std::vector<uint16_t> &dst) { // [ot][k-step][lane][8]: k = 32 ks + 8 (lane >> 4) + e, row lane & 15
+        dst.assign(fw / 2, 0);
+        for (int ot = 0; ot < n->n_ot; ot++)
+            for (int ks = 0; ks < n->fc_ksteps; ks++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < 8; e++) {
+                        const int k = 32 * ks + 8 * (lane >> 4) + e;
+                        if (k >= HW * n->xc) continue;
+                        const int k64 = (k / n->xc) * AZ_NET_XOUT_C + k % n->xc;
+                        dst[(((size_t)ot * n->fc_ksteps + ks) * 64 + lane) * 8 + e] =
+                            src[(((size_t)ot * ks64 + k64 / 32) * 64 + ((k64 % 32) / 8) * 16 + (lane & 15)) * 8 + k64 % 8];
+                    }
+    };
     int rc = AZ_OK;
     auto up = [&](void **dst, const void *src, size_t bytes) {
         if (rc != AZ_OK) return;
@@ -519,8 +541,17 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
         }
         up((void **)&n->epi, e4.data(), e4.size() * sizeof(float));
     }
-    up((void **)&n->fc_w, d.fc_w, fw);
-    if (n->precision == AZ_NET_PREC_F16X3) up((void **)&n->fc_w_lo, d.fc_w_lo, fw);
+    if (n->xc != AZ_NET_XOUT_C) {
+        repack_fc(d.fc_w, fc_re);
+        up((void **)&n->fc_w, fc_re.data(), fw);
+        if (n->precision == AZ_NET_PREC_F16X3) {
+            repack_fc(d.fc_w_lo, fc_re_lo);
+            up((void **)&n->fc_w_lo, fc_re_lo.data(), fw);
+        }
+    } else {
+        up((void **)&n->fc_w, d.fc_w, fw);
+        if (n->precision == AZ_NET_PREC_F16X3) up((void **)&n->fc_w_lo, d.fc_w_lo, fw);
+    }
     up((void **)&n->fc_b, d.fc_b, fb);
     up((void **)&n->skip_w, d.skip_w, 64 * 4 * sizeof(float));
     if (rc != AZ_OK) {
@@ -544,7 +575,8 @@ extern "C" int az_net_reserve(az_net *n, int32_t max_boards) {
     NCHK(n, hipSetDevice(n->d.device));
     if (n->xout) (void)hipFree(n->xout);
     n->xout = nullptr;
-    size_t bytes = (size_t)max_boards * n->d.rows * n->d.cols * AZ_NET_XOUT_C * 2;
+    // (+ 64 bytes: the last k-step of fc1 may reach past a board's row - into the next board's, times zero weights)
+    size_t bytes = (size_t)max_boards * n->d.rows * n->d.cols * n->xc * 2 + 64;
     NCHK(n, hipMalloc((void **)&n->xout, bytes));
     NCHK(n, hipMemset(n->xout, 0, bytes));
     if (n->xout_lo) (void)hipFree(n->xout_lo);
@@ -587,7 +619,7 @@ struct NetDispatch {
 };
 static NetDispatch net_dispatch(const az_net *n, int n_boards) {
     NetDispatch d = {false, false, false, false};
-    const int HW = n->d.rows * n->d.cols, ksteps = HW * AZ_NET_XOUT_C / 32;
+    const int ksteps = n->fc_ksteps;
     if (n->precision == AZ_NET_PREC_F16X3) {
         d.x3c = n->x3b && n_boards <= AZ_X3C_MAX_BOARDS;
         d.x3c_head = d.x3c && n->n_ot == 1 && ksteps <= 96 && n->d.cols >= 4;
@@ -604,9 +636,8 @@ static NetDispatch net_dispatch(const az_net *n, int n_boards) {
 extern "C" int az_net_issued_mfma_per_board(const az_net *n, int32_t n_boards, double *out) {
     if (!n || !out || n_boards < 1) return AZ_E_INVALID;
     const int n_convs = 2 * n->d.n_blocks, nks = n->r3 < 16 ? 15 : AZ_NET_KSTEPS;
-    const int HW = n->d.rows * n->d.cols;
     const NetDispatch dp = net_dispatch(n, n_boards);
-    const double head = (double)n->n_ot * (HW * AZ_NET_XOUT_C / 32) / 16.0; // one MFMA per (output tile, k-step) per 16 boards
+    const double head = (double)n->n_ot * n->fc_ksteps / 16.0; // one MFMA per (output tile, k-step) per 16 boards
     // a column tile on the x3b scheme: conv 0: 4 k-steps x (9 + 2 T); then 15 x 9 + 2 x (2 T + 3 X) + 2 T (gather k-step)
     const double per_tile = AZ_NET_K0STEPS * 11 + (double)(n_convs - 1) * (15 * 9 + 2 * 5 + 2);
     if (n->precision == AZ_NET_PREC_F16X3) {
@@ -655,7 +686,8 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     hp.HW = n->d.rows * n->d.cols;
     hp.A = n->d.num_actions;
     hp.n_ot = n->n_ot;
-    hp.ksteps = hp.HW * AZ_NET_XOUT_C / 32;
+    hp.K = hp.HW * n->xc;
+    hp.ksteps = n->fc_ksteps;
     hp.n_boards = n_boards;
     hp.x = n->xout;
     hp.x_lo = n->xout_lo;
@@ -689,6 +721,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
         tp.obs = obs;
         tp.xout = n->xout;
         tp.xout_lo = n->xout_lo;
+        tp.xout_c = n->xc;
         const int grid = (n_boards + 3) / 4;
         const NetDispatch dp = net_dispatch(n, n_boards);
         const bool x3c = dp.x3c; // small batch: one board per workgroup (az_tower_x3c.h)
@@ -744,6 +777,7 @@ extern "C" int az_net_forward(az_net *n, const float *obs, float *priors, float 
     tp.obs = obs;
     tp.xout = n->xout;
     tp.xout_lo = nullptr;
+    tp.xout_c = n->xc;
     tp.fc_w = nullptr;
     int per_wg = g.waves * g.bpw, grid = (n_boards + per_wg - 1) / per_wg;
     hipError_t s;
@@ -771,13 +805,18 @@ extern "C" int az_net_read_tower(az_net *n, float *out, int32_t n_boards) {
     if (!n || !out || n_boards < 1 || n_boards > n->max_boards) return AZ_E_INVALID;
     NCHK(n, hipSetDevice(n->d.device));
     NCHK(n, hipDeviceSynchronize());
-    size_t cnt = (size_t)n_boards * n->d.rows * n->d.cols * AZ_NET_XOUT_C;
+    // out: [n_boards][H*W][AZ_NET_XOUT_C] whatever the stride on the device (channels past it read as zero)
+    const size_t cells = (size_t)n_boards * n->d.rows * n->d.cols, cnt = cells * n->xc;
+    const int nc = n->xc < AZ_NET_XOUT_C ? n->xc : AZ_NET_XOUT_C;
     std::vector<_Float16> h(cnt);
     NCHK(n, hipMemcpy(h.data(), n->xout, cnt * 2, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < cnt; i++) out[i] = (float)h[i];
+    for (size_t i = 0; i < cells * AZ_NET_XOUT_C; i++) out[i] = 0.f;
+    for (size_t c = 0; c < cells; c++)
+        for (int ch = 0; ch < nc; ch++) out[c * AZ_NET_XOUT_C + ch] = (float)h[c * n->xc + ch];
     if (n->precision == AZ_NET_PREC_F16X3) { // hi + lo / 2048
         NCHK(n, hipMemcpy(h.data(), n->xout_lo, cnt * 2, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < cnt; i++) out[i] += (float)h[i] * (1.0f / 2048.0f);
+        for (size_t c = 0; c < cells; c++)
+            for (int ch = 0; ch < nc; ch++) out[c * AZ_NET_XOUT_C + ch] += (float)h[c * n->xc + ch] * (1.0f / 2048.0f);
     }
     return AZ_OK;
 }

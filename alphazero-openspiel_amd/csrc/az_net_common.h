@@ -34,6 +34,7 @@ struct TowerParams {
     const float *obs;
     _Float16 *xout;
     _Float16 *xout_lo; // f16x3: lo halves of the tower output
+    int xout_c;        // channel stride of xout: AZ_NET_XOUT_C, or 52 where fc1 is az_head_gemm_kernel (az_net_create)
     // az_tower_x3c_kernel only: fc1 + softmax + tanh inside the launch when fc_w is set (one output tile: A + 1 <= 16)
     const _Float16 *fc_w, *fc_w_lo; // [ksteps][64][8] (az_head_params.h)
     const float *fc_b;

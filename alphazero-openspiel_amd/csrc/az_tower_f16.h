@@ -265,7 +265,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void az_tower_kernel(TowerPa
                         xres[mt][nt] = xv;
                         if (KIND == 2) {
                             o = __builtin_convertvector(xv, half4);
-                            if (grow[nt] >= 0) *(half4 *)(p.xout + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = o;
+                            if (grow[nt] >= 0 && co0 < p.xout_c) *(half4 *)(p.xout + (size_t)grow[nt] * p.xout_c + co0) = o;
                             continue;
                         }
                         o = lrelu_h4(__builtin_convertvector(__builtin_elementwise_fma(sc, xv, sh), half4)); // one v_pk_fma_f32 per pair

@@ -264,9 +264,9 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3_kernel(TowerParams p) {
                         if (KIND == 2) {
                             half4 hi, lo;
                             split4(xv, hi, lo);
-                            if (grow[nt] >= 0) {
-                                *(half4 *)(p.xout + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = hi;
-                                *(half4 *)(p.xout_lo + (size_t)grow[nt] * AZ_NET_XOUT_C + co0) = lo;
+                            if (grow[nt] >= 0 && co0 < p.xout_c) {
+                                *(half4 *)(p.xout + (size_t)grow[nt] * p.xout_c + co0) = hi;
+                                *(half4 *)(p.xout_lo + (size_t)grow[nt] * p.xout_c + co0) = lo;
                             }
                             continue;
                         }

@@ -476,11 +476,12 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                     if constexpr (KIND == 2) {
                         half4 hi, lo;
                         split4(xv, hi, lo);
-                        if ((opaque((int)livem) >> nt) & 1) { // a board of the batch (the column's global row, looked up again: once per forward)
+                        if (((opaque((int)livem) >> nt) & 1) && co0 < p.xout_c) { // a board of the batch (the column's global row, looked up again: once per
+                                                                                // forward); channels past the stride (tile T, q > 0) are not stored
                             const int e = p.xd_pos[tile[nt] * 16 + l15];
                             const size_t gr = (size_t)(blockIdx.x * p.xd_nb + (e >> 8)) * p.HW + (e & 255);
-                            *(half4 *)(p.xout + gr * AZ_NET_XOUT_C + co0) = hi;
-                            *(half4 *)(p.xout_lo + gr * AZ_NET_XOUT_C + co0) = lo;
+                            *(half4 *)(p.xout + gr * p.xout_c + co0) = hi;
+                            *(half4 *)(p.xout_lo + gr * p.xout_c + co0) = lo;
                         }
                         return;
                     }
