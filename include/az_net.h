@@ -37,7 +37,7 @@ extern "C" {
 
 #define AZ_NET_CPAD 56      /* channels per LDS cell: 7 groups of 8 (n_filters <= 56) */
 #define AZ_NET_KSTEPS 16    /* 32-deep MFMA k-steps per conv: 64 groups x 8 */
-#define AZ_NET_XOUT_C 64    /* channel stride of fc_w's K index and of az_net_read_tower's rows (the device may keep fewer: az_net.hip) */
+#define AZ_NET_XOUT_C 64    /* channel stride of the tower output handed to the FC kernel */
 
 typedef struct az_net_desc {
     int32_t struct_size;
