@@ -54,6 +54,9 @@ def _nets():
         # 4 rows = 2 row-pair tiles per board: the 3-tile kernel must mask its third tile
         "bt4x5_2block": (games.load_game("breakthrough(rows=4,columns=5)"),
                          Net([3, 4, 5], 240, n_blocks=2, n_filters=40).eval()),
+        # fc1 as a GEMM (az_head_gemm_kernel) with more filters than its 52-channel stride holds: the tower output keeps 64 channels
+        "bt4x8_54f_2block": (games.load_game("breakthrough(rows=4,columns=8)"),
+                             Net([3, 4, 8], 384, n_blocks=2, n_filters=54).eval()),
     }
 
 
@@ -134,7 +137,10 @@ def test_fused_forward_matches_the_reference_held_outputs(tag, shape, A, precisi
                                    ("c4_10block", 300), ("bt8_2block", 37), ("bt5x4_3block", 50),
                                    ("bt4x5_2block", 3), ("bt4x5_2block", 130), ("c4_10block", 4096),
                                    ("c4_56f_2block", 33), ("c4_56f_2block", 2100), ("bt5x5_2block", 70),
-                                   ("bt6_10block", 4096), ("bt8_20block", 2048)])
+                                   ("bt6_10block", 4096), ("bt8_20block", 2048),
+                                   # the edges of az_head_gemm_kernel's 128-board tiles and 16-board MFMA tiles
+                                   ("bt8_2block", 1), ("bt8_2block", 128), ("bt6_ckpt", 129), ("bt5x5_2block", 255),
+                                   ("bt4x8_54f_2block", 140)])
 def test_fused_forward_matches_torch(tag, n):
     game, net = _nets()[tag]
     boards = _random_boards(game, n, 7)
@@ -165,7 +171,9 @@ def test_fused_forward_matches_torch(tag, n):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,n", [("c4_ckpt", 157), ("c4_10block", 4096), ("bt6_ckpt", 40), ("bt6_10block", 4096),
                                    ("bt8_2block", 37), ("bt8_20block", 2048), ("bt5x4_3block", 50), ("bt4x5_2block", 130),
-                                   ("c4_56f_2block", 33), ("bt5x5_2block", 70)])
+                                   ("c4_56f_2block", 33), ("bt5x5_2block", 70),
+                                   ("bt8_2block", 1), ("bt8_2block", 128), ("bt6_ckpt", 129), ("bt5x5_2block", 255),
+                                   ("bt4x8_54f_2block", 140)])
 def test_fused_f32x_forward_is_fp32_grade(tag, n):
     """precision="f32x" (AZ_NET_PREC_F16X3: split-fp16 operands, three MFMAs per product) against an fp64 evaluation of
     the same net: the error must be of the order of torch-fp32's own error against fp64 - i.e. the path is a stand-in
