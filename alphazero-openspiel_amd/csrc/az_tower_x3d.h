@@ -132,7 +132,13 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
         tap = tap > 8 ? 8 : tap;
         return ((tap / 3 - 1) * VV::RS + (tap % 3 - 1)) * 4;
     };
-    auto sel4 = [](int qq, int c0, int c1, int c2, int c3) { return qq == 0 ? c0 : qq == 1 ? c1 : qq == 2 ? c2 : c3; };
+    // q = 2 b1 + b0 picks one of four compile-time constants - by arithmetic: as nested ?: on the (opaque) lane-variant q the compiler
+    // built exec-mask branches, four per k-step, every one of them the end of a scheduling region: 3-4 % of the kernel and 13 spilled
+    // registers of the 6x6 variant.  (Bit masks instead of the multiplies: fewer registers, the same time.)
+    auto sel4 = [](int qq, int c0, int c1, int c2, int c3) {
+        const int b0 = qq & 1, b1 = qq >> 1;
+        return c0 + b0 * (c1 - c0) + b1 * (c2 - c0) + (b0 & b1) * (c3 - c2 - c1 + c0);
+    };
 
     auto split4 = [&](const f32x4 &v, half4 &hi, half4 &lo) { split4_f16x3(v, hi, lo); }; // x -> (hi, lo): az_net_common.h
     __syncthreads(); // the zeroes are down before the input planes are written
