@@ -532,12 +532,16 @@ extern "C" int az_net_create(const az_net_desc *desc, az_net **out) {
         up((void **)&n->conv_w, dev.data(), dev.size());
         }
     }
-    {   // [conv][3][64] (ABI) -> [conv][4][64] with the NEXT conv's bias in row 3 (what the kernel's ring slot holds)
+    {   // [conv][3][64] (ABI) -> [conv][4][64] with the NEXT conv's bias in row 3 (what the kernel's ring slot holds; f32x: x 2048)
         int nc = 2 * d.n_blocks;
         std::vector<float> e4((size_t)nc * 256, 0.f);
         for (int c = 0; c < nc; c++) {
             memcpy(&e4[(size_t)c * 256], d.conv_epi + (size_t)c * 192, 192 * sizeof(float));
             if (c + 1 < nc) memcpy(&e4[(size_t)c * 256 + 192], d.conv_epi + (size_t)(c + 1) * 192, 64 * sizeof(float));
+            // fp32-grade towers: an accumulator holds 2048 x the conv (X3_WSCALE), so its initial value is 2048 x the bias - scaled here
+            // (exact), not by two multiplies per output tile in every epilogue
+            if (n->precision == AZ_NET_PREC_F16X3)
+                for (int i = 0; i < 64; i++) e4[(size_t)c * 256 + 192 + i] *= X3_WSCALE;
         }
         up((void **)&n->epi, e4.data(), e4.size() * sizeof(float));
     }

@@ -157,6 +157,9 @@ template <int OFF> __device__ __forceinline__ void lds_read64_off(f32x2 &dst, un
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));
 }
 __device__ __forceinline__ void lds_write64(unsigned lds_byte_addr, f32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(lds_byte_addr), "v"(v) : "memory"); }
+template <int OFF> __device__ __forceinline__ void lds_write64_off(unsigned lds_byte_addr, f32x2 v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(lds_byte_addr), "v"(v), "n"(OFF) : "memory");
+}
 #define READ_A(dst, addr, off) lds_read128_off<(off)>(dst, addr)
 template <int OFF> __device__ __forceinline__ void lds_read32_off(unsigned &dst, unsigned lds_byte_addr) {
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF));

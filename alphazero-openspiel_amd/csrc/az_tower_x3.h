@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3_kernel(TowerParams p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
                     f32x4 v = acc[mt][nt] + acc2[mt][nt] * INV_SPLIT;
-                    acc[mt][nt] = next_bias;
+                    acc[mt][nt] = next_bias * INV_SPLIT; // (the ring holds 2048 x the bias, for the single-accumulator kernels)
                     acc2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     f32x4 o;
                     if (KIND == 0) {

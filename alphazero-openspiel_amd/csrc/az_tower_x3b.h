@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
                     f32x4 v;
                     if (mt < 3) {
                         v = acc[mt][nt] * INV_SPLIT;
-                        acc[mt][nt] = next_bias * X3_WSCALE;
+                        acc[mt][nt] = next_bias; // (2048 x the next conv's bias: scaled on the host)
                     } else { // tile T, lanes q == 0: rows hi 48, hi 49, lo 48, lo 49 of the gather k-step (+ bias), plus the tap planes
                         v = (f32x4){(acc[3][nt][0] + acc[3][nt][2]) * INV_SPLIT, (acc[3][nt][1] + acc[3][nt][3]) * INV_SPLIT, 0.f, 0.f};
                         if constexpr (!IS_FIRST) {
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void az_tower_x3b_kernel(TowerParams p) {
                             v[1] += s49[nt][1];
                         }
                         if (q != 0) v = (f32x4){0.f, 0.f, 0.f, 0.f}; // (rows 4..15: centre-tap rows / unused)
-                        acc[3][nt] = q == 0 ? (f32x4){next_bias[0] * X3_WSCALE, next_bias[1] * X3_WSCALE, 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        acc[3][nt] = q == 0 ? (f32x4){next_bias[0], next_bias[1], 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
                     f32x4 o;
                     if (KIND == 0) {

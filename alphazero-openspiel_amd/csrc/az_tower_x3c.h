@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
                     f32x4 v;
                     if constexpr (!TX) {
                         v = acc[nt] * INV_SPLIT;
-                        acc[nt] = next_bias * X3_WSCALE;
+                        acc[nt] = next_bias; // (2048 x the next conv's bias: scaled on the host)
                     } else {
                         v = (f32x4){(acc[nt][0] + acc[nt][2]) * INV_SPLIT, (acc[nt][1] + acc[nt][3]) * INV_SPLIT, 0.f, 0.f};
                         if constexpr (!IS_FIRST) {
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256 * BPW, BPW) void az_tower_x3c_kernel(TowerParam
                             v[1] += s49[nt][1];
                         }
                         if (q != 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        acc[nt] = q == 0 ? (f32x4){next_bias[0] * X3_WSCALE, next_bias[1] * X3_WSCALE, 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        acc[nt] = q == 0 ? (f32x4){next_bias[0], next_bias[1], 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
                     f32x4 o;
                     if (KIND == 0) {

@@ -452,18 +452,19 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
             });
             // ---- epilogue, in fp32; the result is split into (hi, lo) again (az_tower_x3b.h: the same arithmetic) -------------
             const unsigned ep_base = lds_base + X3D::OFF_EPI + (conv & 1) * 1024 + q * 16;
-            auto unit = [&](auto kind, auto tt_c, f32x4 &a, f32x4 &xr, const f32x2 &s, const int mt, const int nt,
-                            const f32x4 &sc, const f32x4 &sh, const f32x4 &next_bias) {
+            // sa_hi / sa_lo: LDS address of the lane's quarter-octet (q) of output-channel tile 0 in the tile's cell, hi and lo planes (the
+            // output-channel tile is an immediate offset of the store: one address per tile and plane set, not three instructions per store)
+            auto unit = [&](auto kind, auto tt_c, f32x4 &a, f32x4 &xr, const f32x2 &s, auto mt_c, const int nt,
+                            const f32x4 &sc, const f32x4 &sh, const f32x4 &next_bias, const unsigned sa_hi, const unsigned sa_lo) {
                 constexpr int KIND = decltype(kind)::value; // 0: conv1, 1: conv2 (not last), 2: last conv
                 constexpr bool TT = decltype(tt_c)::value;  // tile T
-                // (opaque: addresses derived from the per-tile tables are invariant across convs, and hoisted out of the conv loop every
-                //  (tile, output-channel tile) pair would hold registers for the whole kernel)
+                constexpr int mt = decltype(mt_c)::value;
                 const int co0 = 16 * mt + 4 * q;
-                const int woff = (2 * mt + (q >> 1)) * plane_b + (q & 1) * 8;
                 f32x4 v;
+                const f32x4 a_in = a;
                 if constexpr (!TT) {
                     v = a * INV_SPLIT;
-                    a = next_bias * X3_WSCALE;
+                    a = next_bias; // (2048 x the next conv's bias: scaled on the host)
                 } else { // lanes q == 0: rows hi 48, hi 49, lo 48, lo 49 of the gather k-step (+ bias), plus the tap planes
                     v = (f32x4){(a[0] + a[2]) * INV_SPLIT, (a[1] + a[3]) * INV_SPLIT, 0.f, 0.f};
                     if constexpr (!IS_FIRST) {
@@ -471,13 +472,16 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                         v[1] += s[1];
                     }
                     if (q != 0) v = (f32x4){0.f, 0.f, 0.f, 0.f}; // (rows 4..15: centre-tap rows / unused)
-                    a = q == 0 ? (f32x4){next_bias[0] * X3_WSCALE, next_bias[1] * X3_WSCALE, 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    a = q == 0 ? (f32x4){next_bias[0], next_bias[1], 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
                 f32x4 o;
                 if constexpr (KIND == 0) {
                     o = __builtin_elementwise_max(v, v * 0.01f);
                 } else {
-                    f32x4 xv = xr + v;
+                    // xr + a / 2048 in one instruction: a / 2048 is exact (a power of two), so the fma has the bits of multiply-then-add
+                    f32x4 xv;
+                    if constexpr (!TT) xv = __builtin_elementwise_fma(a_in, (f32x4){INV_SPLIT, INV_SPLIT, INV_SPLIT, INV_SPLIT}, xr);
+                    else xv = xr + v;
                     xr = xv;
                     if constexpr (KIND == 2) {
                         half4 hi, lo;
@@ -507,9 +511,8 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                         *(unsigned *)(lds + a6 + LO_OFF) = __builtin_bit_cast(u32x2, lo)[0];
                     }
                 } else {
-                    const int a0 = opaque((int)baseL[nt]) - (int)lds_base + woff;
-                    *(half4 *)(lds + a0) = hi;
-                    *(half4 *)(lds + a0 + LO_OFF) = lo;
+                    lds_write64_off<2 * mt * plane_b>(sa_hi, __builtin_bit_cast(f32x2, hi));
+                    lds_write64_off<2 * mt * plane_b>(sa_lo, __builtin_bit_cast(f32x2, lo));
                 }
             };
             auto epilogue = [&](auto kind) {
@@ -529,13 +532,25 @@ __global__ __launch_bounds__(512, 2) void az_tower_x3d_kernel(TowerParams p) {
                     sc[mt] = sh[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     params(mt, sc[mt], sh[mt], nb[mt]);
                 }
+                // (opaque: the addresses are invariant across convs, and hoisted out of the conv loop they would hold registers for the whole kernel)
+                unsigned sa_hi[NTA], sa_lo[NTA];
+                const unsigned qoff = (unsigned)((q >> 1) * plane_b + (q & 1) * 8);
 #pragma unroll
-                for (int mt = 0; mt < 3; mt++)
+                for (int nt = 0; nt < NTA; nt++) {
+                    sa_hi[nt] = addr_add((unsigned)opaque((int)baseL[nt]), qoff);
+                    sa_lo[nt] = sa_hi[nt] + LO_OFF;
+                }
+                static_for<3>([&](auto mt_c) {
+                    constexpr int mt = decltype(mt_c)::value;
 #pragma unroll
-                    for (int nt = 0; nt < NTW; nt++) unit(kind, std::false_type{}, acc[mt][nt], xres[mt][nt], s0, mt, nt, sc[mt], sh[mt], nb[mt]);
+                    for (int nt = 0; nt < NTW; nt++) unit(kind, std::false_type{}, acc[mt][nt], xres[mt][nt], s0, mt_c, nt, sc[mt], sh[mt], nb[mt], sa_hi[nt], sa_lo[nt]);
+                });
 #pragma unroll
-                for (int nt = 0; nt < NTT; nt++) unit(kind, std::true_type{}, accT[nt], xresT[nt], IS_FIRST ? s0 : s49[nt], 3, nt, sc[3], sh[3], nb[3]);
-                if constexpr (EXM) unit(kind, std::false_type{}, acce, xrese, s0, emt, NTW, sc[emt], sh[emt], nb[emt]);
+                for (int nt = 0; nt < NTT; nt++)
+                    unit(kind, std::true_type{}, accT[nt], xresT[nt], IS_FIRST ? s0 : s49[nt], std::integral_constant<int, 3>{}, nt, sc[3], sh[3], nb[3], sa_hi[nt], sa_lo[nt]);
+                if constexpr (EXM)
+                    unit(kind, std::false_type{}, acce, xrese, s0, std::integral_constant<int, EXM ? emt : 0>{}, NTW, sc[emt], sh[emt], nb[emt], sa_hi[NTW], sa_lo[NTW]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the plane stores are untracked asm statements)
             };
             if constexpr (IS_FIRST) epilogue(std::integral_constant<int, 0>{});
             else {
